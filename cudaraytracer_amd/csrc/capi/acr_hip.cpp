@@ -1,0 +1,577 @@
+// Implementation of the C ABI declared in include/acr_hip.h: context and
+// buffer management, scene validation + packing into the device blob
+// (device/device_scene.h), and the kernel launches.
+//
+// There is no CPU fallback anywhere in this file: every compute entry point
+// either launches a HIP kernel or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/acr_hip.h"
+#include "../device/device_scene.h"
+#include "../device/render_params.h"
+
+using acr::dev::RenderParams;
+using acr::dev::SceneHeader;
+using acr::dev::TraceParams;
+
+struct acr_hip_ctx
+{
+	int device = 0;
+	hipStream_t ownStream = nullptr;
+	hipStream_t stream = nullptr;
+	std::string error;
+
+	// scene
+	bool haveScene = false;
+	SceneHeader header{};
+	uint4 *blob = nullptr;
+	size_t blobBytes = 0;
+
+	// camera
+	bool haveCamera = false;
+	acr_camera camera{};
+
+	// context-owned buffers (acr_hip_resize)
+	uint32_t width = 0, height = 0;
+	float4 *screen = nullptr;
+	uint32_t *primid = nullptr;
+	float *hitT = nullptr;
+	int32_t *pixelValues = nullptr;
+
+	// per-launch scratch
+	unsigned long long *counters = nullptr; // device [4]
+	uint32_t *tileIds = nullptr;            // device copy of the tile list
+	std::vector<uint32_t> tileIdsHost;      // stays alive while the async copy reads it
+	size_t tileIdsCap = 0;
+	hipEvent_t evStart = nullptr, evStop = nullptr;
+	bool timed = false;
+	acr_stats stats{};
+	size_t lastSlots = 0; // pixel slots written by the last render
+};
+
+namespace
+{
+	constexpr uint32_t kBlock = 256;
+	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
+	constexpr size_t kLdsBudget = 64 * 1024;
+
+	int fail(acr_hip_ctx *ctx, int code, const char *fmt, ...)
+	{
+		char buf[512];
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(buf, sizeof(buf), fmt, ap);
+		va_end(ap);
+		if (ctx) ctx->error = buf;
+		return code;
+	}
+
+#define ACR_HIP_TRY(ctx, expr)                                                                          \
+	do {                                                                                                \
+		hipError_t e_ = (expr);                                                                         \
+		if (e_ != hipSuccess) return fail(ctx, ACR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+	} while (0)
+
+	uint32_t fbits(float f)
+	{
+		uint32_t u;
+		memcpy(&u, &f, 4);
+		return u;
+	}
+
+	// Walks the nodes reachable from the root and checks what the kernels rely on:
+	// an internal node has both children inside the heap, a leaf's item range is
+	// inside [0, itemCount].
+	bool checkBih(uint32_t depth, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t itemCount, std::string &why)
+	{
+		if (depth < 1 || depth > ACR_MAX_BIH_DEPTH) { why = "BIH depth out of range"; return false; }
+		const uint64_t count = (1ull << depth) - 1;
+		std::vector<uint32_t> todo(1, 0u);
+		while (!todo.empty()) {
+			const uint32_t i = todo.back();
+			todo.pop_back();
+			if (flags[i] & ACR_NODE_LEAF) {
+				if (start[i] <= end[i] && end[i] > itemCount) { why = "leaf item range outside the item array"; return false; }
+				continue;
+			}
+			if ((flags[i] & ACR_NODE_AXIS_MASK) > 2) { why = "node axis > 2"; return false; }
+			if (2ull * i + 2 >= count) { why = "internal node on the last level"; return false; }
+			todo.push_back(2 * i + 2);
+			todo.push_back(2 * i + 1);
+		}
+		return true;
+	}
+
+	void putNode(uint4 &dst, float left, float right, uint32_t start, uint32_t end, uint8_t flags)
+	{
+		dst.x = fbits(left);
+		dst.y = fbits(right);
+		dst.z = start;
+		dst.w = (end & acr::dev::kNodeEndMask) | (uint32_t(flags & ACR_NODE_AXIS_MASK) << acr::dev::kNodeAxisShift) |
+		        ((flags & ACR_NODE_LEAF) ? acr::dev::kNodeLeafBit : 0u);
+	}
+
+	struct LaunchPlan
+	{
+		int ldsMode;
+		uint32_t stackSlot;
+		size_t ldsBytes;
+	};
+
+	// Decides how much of the scene a workgroup stages into LDS.
+	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels)
+	{
+		const size_t stackFloats = size_t(h.scene_depth + h.max_mesh_depth + 3 * colorLevels) * kBlock;
+		const size_t stackBytes = stackFloats * 4;
+		LaunchPlan p;
+		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {
+			p.ldsMode = 2;
+			p.stackSlot = h.total_slots;
+		} else if (size_t(h.small_slots) * 16 + stackBytes <= kLdsBudget) {
+			p.ldsMode = 1;
+			p.stackSlot = h.small_slots;
+		} else {
+			p.ldsMode = 0;
+			p.stackSlot = 0;
+		}
+		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
+		return p;
+	}
+} // namespace
+
+extern "C" {
+
+int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
+{
+	if (!out) return ACR_ERR_INVALID;
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || device_ordinal < 0 || device_ordinal >= count) return ACR_ERR_HIP;
+	acr_hip_ctx *ctx = new acr_hip_ctx();
+	ctx->device = device_ordinal;
+	if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->counters), 4 * sizeof(unsigned long long)) != hipSuccess ||
+	    hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess) {
+		acr_hip_destroy(ctx);
+		return ACR_ERR_HIP;
+	}
+	ctx->stream = ctx->ownStream;
+	*out = ctx;
+	return ACR_OK;
+}
+
+void acr_hip_destroy(acr_hip_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->ownStream) (void)hipStreamSynchronize(ctx->ownStream);
+	(void)hipFree(ctx->blob);
+	(void)hipFree(ctx->screen);
+	(void)hipFree(ctx->primid);
+	(void)hipFree(ctx->hitT);
+	(void)hipFree(ctx->pixelValues);
+	(void)hipFree(ctx->counters);
+	(void)hipFree(ctx->tileIds);
+	if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+	if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+	if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+	delete ctx;
+}
+
+const char *acr_hip_last_error(const acr_hip_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream)
+{
+	if (!ctx) return ACR_ERR_INVALID;
+	ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+	return ACR_OK;
+}
+
+int acr_hip_sync(acr_hip_ctx *ctx)
+{
+	if (!ctx) return ACR_ERR_INVALID;
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return ACR_OK;
+}
+
+int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
+{
+	if (!ctx || !s) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	std::string why;
+	if (s->num_objects >= (1u << 28) || s->num_triangles >= (1u << 28) || s->num_mesh_nodes >= (1u << 28))
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "scene too large for 28-bit item indices");
+	if (!s->snode_start || !s->snode_end || !s->snode_left || !s->snode_right || !s->snode_flags)
+		return fail(ctx, ACR_ERR_INVALID, "scene BIH arrays missing");
+	if (!checkBih(s->scene_depth, s->snode_start, s->snode_end, s->snode_flags, s->num_objects, why))
+		return fail(ctx, ACR_ERR_INVALID, "scene BIH: %s", why.c_str());
+	if (s->num_objects && (!s->obj_transform || !s->obj_inv_transform || !s->obj_normal_transform || !s->obj_inv_normal_transform ||
+	                       !s->obj_mesh_begin || !s->obj_mesh_count))
+		return fail(ctx, ACR_ERR_INVALID, "object arrays missing");
+	for (uint32_t i = 0; i < s->num_objects; i++) {
+		if (uint64_t(s->obj_mesh_begin[i]) + s->obj_mesh_count[i] > s->num_obj_mesh_ids)
+			return fail(ctx, ACR_ERR_INVALID, "object %u: mesh list outside obj_mesh_ids", i);
+	}
+	for (uint32_t i = 0; i < s->num_obj_mesh_ids; i++)
+		if (s->obj_mesh_ids[i] >= s->num_meshes) return fail(ctx, ACR_ERR_INVALID, "obj_mesh_ids[%u] out of range", i);
+	uint32_t maxMeshDepth = 1;
+	for (uint32_t m = 0; m < s->num_meshes; m++) {
+		const uint32_t d = s->mesh_depth[m];
+		if (d < 1 || d > ACR_MAX_BIH_DEPTH) return fail(ctx, ACR_ERR_UNSUPPORTED, "mesh %u: BIH depth %u", m, d);
+		const uint64_t count = (1ull << d) - 1;
+		if (uint64_t(s->mesh_node_begin[m]) + count > s->num_mesh_nodes) return fail(ctx, ACR_ERR_INVALID, "mesh %u: nodes outside the pool", m);
+		const uint32_t nb = s->mesh_node_begin[m];
+		const uint32_t triBegin = s->mesh_tri_begin[m];
+		if (triBegin > s->num_triangles) return fail(ctx, ACR_ERR_INVALID, "mesh %u: tri_begin out of range", m);
+		if (!checkBih(d, s->mnode_start + nb, s->mnode_end + nb, s->mnode_flags + nb, s->num_triangles - triBegin, why))
+			return fail(ctx, ACR_ERR_INVALID, "mesh %u BIH: %s", m, why.c_str());
+		if (s->mesh_material[m] >= s->num_materials) return fail(ctx, ACR_ERR_INVALID, "mesh %u: material index out of range", m);
+		if (d > maxMeshDepth) maxMeshDepth = d;
+	}
+	for (uint32_t i = 0; i < s->num_lights; i++)
+		if (s->light_type[i] < 0 || s->light_type[i] > 2) return fail(ctx, ACR_ERR_INVALID, "light %u: unknown type", i);
+
+	// ---- pack ----
+	SceneHeader h{};
+	const uint32_t snodeCount = (1u << s->scene_depth) - 1;
+	uint32_t at = 0;
+	h.off_snodes = at; at += snodeCount;
+	h.off_objects = at; at += s->num_objects * acr::dev::kObjectSlots;
+	h.off_objmesh = at; at += (s->num_obj_mesh_ids + 3) / 4;
+	h.off_meshes = at; at += s->num_meshes * acr::dev::kMeshSlots;
+	h.off_materials = at; at += s->num_materials * acr::dev::kMaterialSlots;
+	h.off_lights = at; at += s->num_lights * acr::dev::kLightSlots;
+	h.small_slots = at;
+	h.off_mnodes = at; at += s->num_mesh_nodes;
+	h.off_tris = at; at += s->num_triangles * acr::dev::kTriSlots;
+	h.off_normals = at; at += s->num_triangles * acr::dev::kNormalSlots;
+	h.total_slots = at;
+	h.scene_depth = s->scene_depth;
+	h.max_mesh_depth = maxMeshDepth;
+	h.num_objects = s->num_objects;
+	h.num_meshes = s->num_meshes;
+	h.num_materials = s->num_materials;
+	h.num_lights = s->num_lights;
+	h.num_triangles = s->num_triangles;
+	memcpy(h.scene_min, s->scene_min, 12);
+	memcpy(h.scene_max, s->scene_max, 12);
+
+	std::vector<uint4> blob(h.total_slots ? h.total_slots : 1, make_uint4(0, 0, 0, 0));
+	for (uint32_t i = 0; i < snodeCount; i++)
+		putNode(blob[h.off_snodes + i], s->snode_left[i], s->snode_right[i], s->snode_start[i], s->snode_end[i], s->snode_flags[i]);
+	for (uint32_t i = 0; i < s->num_objects; i++) {
+		uint32_t *w = reinterpret_cast<uint32_t *>(&blob[h.off_objects + i * acr::dev::kObjectSlots]);
+		memcpy(w, s->obj_inv_transform + 16 * size_t(i), 64);
+		memcpy(w + 16, s->obj_inv_normal_transform + 9 * size_t(i), 36);
+		w[25] = s->obj_mesh_begin[i];
+		w[26] = s->obj_mesh_count[i];
+		memcpy(w + 28, s->obj_transform + 16 * size_t(i), 64);
+		memcpy(w + 44, s->obj_normal_transform + 9 * size_t(i), 36);
+	}
+	if (s->num_obj_mesh_ids) memcpy(&blob[h.off_objmesh], s->obj_mesh_ids, 4 * size_t(s->num_obj_mesh_ids));
+	for (uint32_t m = 0; m < s->num_meshes; m++) {
+		uint4 *q = &blob[h.off_meshes + m * acr::dev::kMeshSlots];
+		q[0] = make_uint4(fbits(s->mesh_min[3 * m]), fbits(s->mesh_min[3 * m + 1]), fbits(s->mesh_min[3 * m + 2]), s->mesh_material[m]);
+		q[1] = make_uint4(fbits(s->mesh_max[3 * m]), fbits(s->mesh_max[3 * m + 1]), fbits(s->mesh_max[3 * m + 2]), s->mesh_node_begin[m]);
+		q[2] = make_uint4(s->mesh_tri_begin[m], s->mesh_depth[m], 0, 0);
+	}
+	for (uint32_t i = 0; i < s->num_materials; i++) {
+		uint4 *q = &blob[h.off_materials + i * acr::dev::kMaterialSlots];
+		q[0] = make_uint4(fbits(s->mat_ambient[3 * i]), fbits(s->mat_ambient[3 * i + 1]), fbits(s->mat_ambient[3 * i + 2]), fbits(s->mat_refractive_index[i]));
+		q[1] = make_uint4(fbits(s->mat_diffuse[3 * i]), fbits(s->mat_diffuse[3 * i + 1]), fbits(s->mat_diffuse[3 * i + 2]), 0);
+		q[2] = make_uint4(fbits(s->mat_specular[3 * i]), fbits(s->mat_specular[3 * i + 1]), fbits(s->mat_specular[3 * i + 2]), 0);
+	}
+	for (uint32_t i = 0; i < s->num_lights; i++) {
+		uint4 *q = &blob[h.off_lights + i * acr::dev::kLightSlots];
+		const float *pos = s->light_position + 3 * i, *dir = s->light_direction + 3 * i, *dif = s->light_diffuse + 3 * i;
+		const float *att = s->light_attenuation + 3 * i, *cone = s->light_cone + 2 * i;
+		q[0] = make_uint4(fbits(pos[0]), fbits(pos[1]), fbits(pos[2]), uint32_t(s->light_type[i]));
+		q[1] = make_uint4(fbits(dir[0]), fbits(dir[1]), fbits(dir[2]), fbits(att[0]));
+		q[2] = make_uint4(fbits(dif[0]), fbits(dif[1]), fbits(dif[2]), fbits(att[1]));
+		q[3] = make_uint4(fbits(att[2]), fbits(cone[0]), fbits(cone[1]), 0);
+	}
+	for (uint32_t i = 0; i < s->num_mesh_nodes; i++)
+		putNode(blob[h.off_mnodes + i], s->mnode_left[i], s->mnode_right[i], s->mnode_start[i], s->mnode_end[i], s->mnode_flags[i]);
+	for (uint32_t i = 0; i < s->num_triangles; i++) {
+		const float *a = s->tri_p0 + 3 * size_t(i), *b = s->tri_p1 + 3 * size_t(i), *c = s->tri_p2 + 3 * size_t(i);
+		// e1 = b - a, e2 = c - a: the two subtractions of math.h:132-133, done once here
+		const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+		const float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+		uint4 *q = &blob[h.off_tris + size_t(i) * acr::dev::kTriSlots];
+		q[0] = make_uint4(fbits(a[0]), fbits(a[1]), fbits(a[2]), fbits(e1[0]));
+		q[1] = make_uint4(fbits(e1[1]), fbits(e1[2]), fbits(e2[0]), fbits(e2[1]));
+		q[2] = make_uint4(fbits(e2[2]), s->tri_prim_id ? s->tri_prim_id[i] : i, 0, 0);
+		const float *n0 = s->tri_n0 + 3 * size_t(i), *n1 = s->tri_n1 + 3 * size_t(i), *n2 = s->tri_n2 + 3 * size_t(i);
+		uint4 *n = &blob[h.off_normals + size_t(i) * acr::dev::kNormalSlots];
+		n[0] = make_uint4(fbits(n0[0]), fbits(n0[1]), fbits(n0[2]), fbits(n1[0]));
+		n[1] = make_uint4(fbits(n1[1]), fbits(n1[2]), fbits(n2[0]), fbits(n2[1]));
+		n[2] = make_uint4(fbits(n2[2]), 0, 0, 0);
+	}
+
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->blob) {
+		ACR_HIP_TRY(ctx, hipFree(ctx->blob));
+		ctx->blob = nullptr;
+	}
+	ctx->haveScene = false;
+	ctx->blobBytes = blob.size() * sizeof(uint4);
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->blob), ctx->blobBytes));
+	ACR_HIP_TRY(ctx, hipMemcpy(ctx->blob, blob.data(), ctx->blobBytes, hipMemcpyHostToDevice));
+	ctx->header = h;
+	ctx->haveScene = true;
+	return ACR_OK;
+}
+
+int acr_hip_set_camera(acr_hip_ctx *ctx, const acr_camera *camera)
+{
+	if (!ctx || !camera) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	ctx->camera = *camera;
+	ctx->haveCamera = true;
+	return ACR_OK;
+}
+
+int acr_hip_get_camera(const acr_hip_ctx *ctx, acr_camera *camera)
+{
+	if (!ctx || !camera || !ctx->haveCamera) return ACR_ERR_INVALID;
+	*camera = ctx->camera;
+	return ACR_OK;
+}
+
+int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height)
+{
+	if (!ctx || width == 0 || height == 0 || uint64_t(width) * height >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "bad frame size");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	(void)hipFree(ctx->screen); ctx->screen = nullptr;
+	(void)hipFree(ctx->primid); ctx->primid = nullptr;
+	(void)hipFree(ctx->hitT); ctx->hitT = nullptr;
+	(void)hipFree(ctx->pixelValues); ctx->pixelValues = nullptr;
+	ctx->width = ctx->height = 0;
+	const size_t n = size_t(width) * height;
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->screen), n * sizeof(float4)));
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->primid), n * sizeof(uint32_t)));
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->hitT), n * sizeof(float)));
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pixelValues), n * sizeof(int32_t)));
+	ACR_HIP_TRY(ctx, hipMemset(ctx->screen, 0, n * sizeof(float4)));
+	ctx->width = width;
+	ctx->height = height;
+	return ACR_OK;
+}
+
+int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev)
+{
+	if (!ctx || !f) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (!ctx->haveScene || !ctx->haveCamera) return fail(ctx, ACR_ERR_NO_SCENE, "render before scene and camera were set");
+	if (f->width == 0 || f->height == 0 || uint64_t(f->width) * f->height >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "bad frame size");
+	if (f->max_bounces > ACR_MAX_BOUNCES) return fail(ctx, ACR_ERR_UNSUPPORTED, "max_bounces %u > %d", f->max_bounces, ACR_MAX_BOUNCES);
+	const bool tiled = f->num_tiles != 0;
+	const bool ownBuffers = screen_dev == nullptr;
+	if (ownBuffers && (tiled || ctx->width != f->width || ctx->height != f->height))
+		return fail(ctx, ACR_ERR_INVALID, "context-owned framebuffer needs acr_hip_resize(width,height) and a full-frame render");
+	uint32_t tilesX = 0, grid = 0;
+	if (tiled) {
+		if (!f->tile_ids || f->tile_w == 0 || f->tile_h == 0 || (f->tile_w & 15u) || (f->tile_h & 15u))
+			return fail(ctx, ACR_ERR_INVALID, "tile list needs tile_ids and tile sizes that are multiples of 16");
+		if (f->pixel_values_dev) return fail(ctx, ACR_ERR_INVALID, "a tile list cannot be combined with a pixel permutation");
+		tilesX = (f->width + f->tile_w - 1) / f->tile_w;
+		const uint32_t tilesY = (f->height + f->tile_h - 1) / f->tile_h;
+		for (uint32_t i = 0; i < f->num_tiles; i++)
+			if (f->tile_ids[i] >= tilesX * tilesY) return fail(ctx, ACR_ERR_INVALID, "tile_ids[%u] out of range", i);
+		const uint64_t g = uint64_t(f->num_tiles) * (f->tile_w / 16) * (f->tile_h / 16);
+		if (g >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "too many tiles");
+		grid = uint32_t(g);
+	} else {
+		grid = ((f->width + 15) / 16) * ((f->height + 15) / 16);
+	}
+
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (tiled) {
+		if (ctx->tileIdsCap < f->num_tiles) {
+			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			(void)hipFree(ctx->tileIds);
+			ctx->tileIds = nullptr;
+			ctx->tileIdsCap = 0;
+			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->tileIds), sizeof(uint32_t) * f->num_tiles));
+			ctx->tileIdsCap = f->num_tiles;
+		}
+		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->tileIdsHost.assign(f->tile_ids, f->tile_ids + f->num_tiles);
+		ACR_HIP_TRY(ctx, hipMemcpyAsync(ctx->tileIds, ctx->tileIdsHost.data(), sizeof(uint32_t) * f->num_tiles, hipMemcpyHostToDevice, ctx->stream));
+	}
+
+	RenderParams p{};
+	p.scene = ctx->header;
+	p.blob = ctx->blob;
+	p.cam_aspect = float(f->width) / float(f->height); // renderer.cu:179
+	p.cam_hfov = ctx->camera.horizontal_fov;
+	memcpy(p.cam_position, ctx->camera.position, 12);
+	memcpy(p.cam_forward, ctx->camera.forward, 12);
+	memcpy(p.cam_up, ctx->camera.up, 12);
+	p.width = f->width;
+	p.height = f->height;
+	p.blocks_x = (f->width + 15) / 16;
+	p.seed = f->seed;
+	p.frames = f->frames;
+	p.max_bounces = f->max_bounces;
+	p.tile_w = f->tile_w;
+	p.tile_h = f->tile_h;
+	p.tiles_x = tilesX;
+	p.num_tiles = f->num_tiles;
+	p.tile_ids = ctx->tileIds;
+	p.pixel_values = f->pixel_values_dev;
+	p.screen = ownBuffers ? ctx->screen : static_cast<float4 *>(screen_dev);
+	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
+	p.hit_t = hit_t_dev ? hit_t_dev : (ownBuffers ? ctx->hitT : nullptr);
+	p.counters = f->collect_stats ? ctx->counters : nullptr;
+
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces ? f->max_bounces : 1);
+	p.lds_stack_slot = plan.stackSlot;
+
+	ctx->timed = f->collect_stats != 0;
+	if (ctx->timed) {
+		ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
+	}
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, grid, plan.ldsBytes, ctx->stream));
+	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
+	ctx->stats = acr_stats{};
+	ctx->stats.lds_bytes = uint32_t(plan.ldsBytes);
+	ctx->stats.scene_in_lds = uint32_t(plan.ldsMode);
+	ctx->stats.grid_blocks = grid;
+	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
+	return ACR_OK;
+}
+
+int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const float *dirs, const float *tmax,
+                       uint8_t *hit, float *t, uint32_t *prim, float *position, float *normal)
+{
+	if (!ctx || !origins || !dirs) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (!ctx->haveScene) return fail(ctx, ACR_ERR_NO_SCENE, "trace before scene upload");
+	if (n == 0) return ACR_OK;
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const size_t v3 = size_t(n) * 12;
+	char *base = nullptr;
+	// one allocation: origins, dirs, tmax | t, prim, position, normal, hit
+	const size_t total = v3 * 2 + size_t(n) * 4 + size_t(n) * 4 + size_t(n) * 4 + v3 * 2 + n;
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&base), total));
+	float *dO = reinterpret_cast<float *>(base);
+	float *dD = reinterpret_cast<float *>(base + v3);
+	float *dTmax = reinterpret_cast<float *>(base + 2 * v3);
+	float *dT = dTmax + n;
+	uint32_t *dPrim = reinterpret_cast<uint32_t *>(dT + n);
+	float *dPos = reinterpret_cast<float *>(dPrim + n);
+	float *dNrm = reinterpret_cast<float *>(reinterpret_cast<char *>(dPos) + v3);
+	uint8_t *dHit = reinterpret_cast<uint8_t *>(reinterpret_cast<char *>(dNrm) + v3);
+	int rc = ACR_OK;
+	hipError_t e = hipMemcpyAsync(dO, origins, v3, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dD, dirs, v3, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dTmax, tmax, size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) {
+		TraceParams p{};
+		p.scene = ctx->header;
+		p.blob = ctx->blob;
+		p.n = n;
+		p.origins = dO; p.dirs = dD; p.tmax = tmax ? dTmax : nullptr;
+		p.hit = dHit; p.t = dT; p.prim = dPrim; p.position = dPos; p.normal = dNrm;
+		const LaunchPlan plan = planLds(ctx->header, 0);
+		p.lds_stack_slot = plan.stackSlot;
+		e = acr_dev_launch_trace(&p, plan.ldsMode, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
+	}
+	if (e == hipSuccess && hit) e = hipMemcpyAsync(hit, dHit, n, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess && t) e = hipMemcpyAsync(t, dT, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess && prim) e = hipMemcpyAsync(prim, dPrim, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess && position) e = hipMemcpyAsync(position, dPos, v3, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess && normal) e = hipMemcpyAsync(normal, dNrm, v3, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) rc = fail(ctx, ACR_ERR_HIP, "trace_rays: %s", hipGetErrorString(e));
+	(void)hipFree(base);
+	return rc;
+}
+
+int acr_hip_read_framebuffer(acr_hip_ctx *ctx, float *rgba, size_t num_floats)
+{
+	if (!ctx || !rgba || !ctx->screen) return fail(ctx, ACR_ERR_INVALID, "no context-owned framebuffer");
+	if (num_floats != size_t(ctx->width) * ctx->height * 4) return fail(ctx, ACR_ERR_INVALID, "size mismatch");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->screen, num_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return ACR_OK;
+}
+
+int acr_hip_read_primid(acr_hip_ctx *ctx, uint32_t *prim, size_t count)
+{
+	if (!ctx || !prim || !ctx->primid) return fail(ctx, ACR_ERR_INVALID, "no context-owned primitive-id buffer");
+	if (count != size_t(ctx->width) * ctx->height) return fail(ctx, ACR_ERR_INVALID, "size mismatch");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipMemcpyAsync(prim, ctx->primid, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return ACR_OK;
+}
+
+int acr_hip_read_hit_t(acr_hip_ctx *ctx, float *t, size_t count)
+{
+	if (!ctx || !t || !ctx->hitT) return fail(ctx, ACR_ERR_INVALID, "no context-owned hit-distance buffer");
+	if (count != size_t(ctx->width) * ctx->height) return fail(ctx, ACR_ERR_INVALID, "size mismatch");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipMemcpyAsync(t, ctx->hitT, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return ACR_OK;
+}
+
+int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
+{
+	if (!ctx || !stats) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->timed) {
+		unsigned long long c[4] = {0, 0, 0, 0};
+		ACR_HIP_TRY(ctx, hipMemcpy(c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost));
+		ctx->stats.rays_primary = c[0];
+		ctx->stats.rays_shadow = c[1];
+		ctx->stats.rays_bounce = c[2];
+		ctx->stats.primary_hits = c[3];
+		float ms = 0;
+		ACR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
+		ctx->stats.kernel_ms = ms;
+	}
+	*stats = ctx->stats;
+	return ACR_OK;
+}
+
+void *acr_hip_framebuffer(acr_hip_ctx *ctx) { return ctx ? ctx->screen : nullptr; }
+
+int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_t *tile_ids, uint32_t num_tiles,
+                          uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, void *frame_dev)
+{
+	if (!ctx || !tiles_dev || !tile_ids || !frame_dev || tile_w == 0 || tile_h == 0 || width == 0 || height == 0)
+		return fail(ctx, ACR_ERR_INVALID, "null or zero argument");
+	if (num_tiles == 0) return ACR_OK;
+	const uint32_t tilesX = (width + tile_w - 1) / tile_w, tilesY = (height + tile_h - 1) / tile_h;
+	for (uint32_t i = 0; i < num_tiles; i++)
+		if (tile_ids[i] >= tilesX * tilesY) return fail(ctx, ACR_ERR_INVALID, "tile_ids[%u] out of range", i);
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->tileIdsCap < num_tiles) {
+		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		(void)hipFree(ctx->tileIds);
+		ctx->tileIds = nullptr;
+		ctx->tileIdsCap = 0;
+		ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->tileIds), sizeof(uint32_t) * num_tiles));
+		ctx->tileIdsCap = num_tiles;
+	}
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->tileIdsHost.assign(tile_ids, tile_ids + num_tiles);
+	ACR_HIP_TRY(ctx, hipMemcpyAsync(ctx->tileIds, ctx->tileIdsHost.data(), sizeof(uint32_t) * num_tiles, hipMemcpyHostToDevice, ctx->stream));
+	ACR_HIP_TRY(ctx, acr_dev_launch_scatter_tiles(tiles_dev, ctx->tileIds, num_tiles, tile_w, tile_h, width, height, frame_dev, ctx->stream));
+	return ACR_OK;
+}
+
+} // extern "C"

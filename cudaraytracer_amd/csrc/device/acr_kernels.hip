@@ -1,0 +1,768 @@
+// Render kernels of the MI355X (gfx950, wave64) renderer core.
+//
+// One work-item per pixel slot; 256-thread workgroups of four waves, each wave
+// an 8x8 pixel square so that the lanes of a wave traverse alike.  The scene
+// blob (device_scene.h) is staged into LDS when it fits, so that after the
+// staging copy the only HBM traffic of a frame is the framebuffer.
+//
+// Everything here follows the reference's arithmetic operation for operation
+// (citations are file:line relative to the reference root); what differs is
+// the machinery around it:
+//   * BIH traversal keeps no box stack.  The reference pushes whole clipped
+//     boxes (bih.h:214-215,256,262).  Here a lane carries the six slab
+//     distances (bound - o) * invD of its CURRENT box in registers, replaces
+//     one of them per descent, and logs the replaced value in an LDS "undo"
+//     column (one float per tree level per lane).  A bitmask remembers at
+//     which levels the right child passed its slab test and is still to be
+//     visited; popping walks the heap index up to that level, restoring one
+//     value per level.  Each slab distance is the same single subtract and
+//     multiply the reference performs (geometry.h:52-66), so every compare
+//     sees identical bits and the visit order (left before right, deepest
+//     pending first, leaf items ascending; bih.h:253-288) is unchanged.
+//   * rayColor's template recursion (renderer.cu:232-324) is a loop; the
+//     per-level direct terms are kept in an LDS column and summed from the
+//     deepest level outwards, the order the recursion adds them.
+//   * Shadow rays stop at the first object that proves occlusion; see
+//     sceneIntersect for why that cannot change the result.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "../math/math.h"
+#include "../math/rng.h"
+#include "device_scene.h"
+#include "render_params.h"
+
+using namespace acr::math;
+using acr::dev::SceneHeader;
+
+namespace acr
+{
+namespace dev
+{
+
+constexpr int kBlock = 256;
+
+extern __shared__ uint4 g_lds[];
+
+__device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
+
+// Scene memory view.  SMALL/LARGE say whether that part of the blob was
+// staged into LDS at the same slot offsets.
+template <bool SMALL_LDS, bool LARGE_LDS>
+struct SceneMem
+{
+	const uint4 *__restrict__ g;
+	__device__ __forceinline__ uint4 small(uint32_t slot) const
+	{
+		if constexpr (SMALL_LDS) return g_lds[slot];
+		else return g[slot];
+	}
+	__device__ __forceinline__ uint4 large(uint32_t slot) const
+	{
+		if constexpr (LARGE_LDS) return g_lds[slot];
+		else return g[slot];
+	}
+};
+
+struct Ray { vec3 o, d; };
+
+// Per-ray constants of the slab test: geometry.h:78-86 / bih.h:223-228
+struct SlabArgs
+{
+	vec3 o, invD;
+	bool sx, sy, sz;
+	__device__ __forceinline__ void init(const Ray &r)
+	{
+		o = r.o;
+		invD = 1.0f / r.d;
+		sx = invD.x < 0;
+		sy = invD.y < 0;
+		sz = invD.z < 0;
+	}
+	__device__ __forceinline__ bool sign(uint32_t axis) const { return axis == 0 ? sx : (axis == 1 ? sy : sz); }
+	// (bound - o) * invD on one axis: the per-plane term of geometry.h:52-66
+	__device__ __forceinline__ float plane(uint32_t axis, float bound) const { return (bound - o[int(axis)]) * invD[int(axis)]; }
+};
+
+// Slab distances of a box, near plane / far plane per axis:
+// near.x = (bounds[sign.x].x - o.x) * invD.x, far.x = (bounds[1-sign.x].x - o.x) * invD.x
+struct SlabBox
+{
+	vec3 nearT, farT;
+	__device__ __forceinline__ void init(const SlabArgs &a, const vec3 &mn, const vec3 &mx)
+	{
+		const vec3 tmn = (mn - a.o) * a.invD;
+		const vec3 tmx = (mx - a.o) * a.invD;
+		nearT = vec3(a.sx ? tmx.x : tmn.x, a.sy ? tmx.y : tmn.y, a.sz ? tmx.z : tmn.z);
+		farT = vec3(a.sx ? tmn.x : tmx.x, a.sy ? tmn.y : tmx.y, a.sz ? tmn.z : tmx.z);
+	}
+};
+
+// geometry.h:50-75 on precomputed plane distances; compare-and-select exactly
+// as written so that NaNs (0 * inf) take the same branches.
+__device__ __forceinline__ bool slabTest(const vec3 &nearT, const vec3 &farT, float tcur)
+{
+	float tmin = nearT.x, tmax = farT.x;
+	const float tymin = nearT.y, tymax = farT.y;
+	if ((tmin > tymax) || (tymin > tmax))
+		return false;
+	if (tymin > tmin)
+		tmin = tymin;
+	if (tymax < tmax)
+		tmax = tymax;
+	const float tzmin = nearT.z, tzmax = farT.z;
+	if ((tmin > tzmax) || (tzmin > tmax))
+		return false;
+	if (tzmin > tmin)
+		tmin = tzmin;
+	if (tzmax < tmax)
+		tmax = tzmax;
+	return tmin < tcur && tmax > epsilon();
+}
+
+__device__ __forceinline__ vec3 withComp(const vec3 &v, uint32_t axis, float f)
+{
+	return vec3(axis == 0 ? f : v.x, axis == 1 ? f : v.y, axis == 2 ? f : v.z);
+}
+
+// bih.h:209-299.  loadNode(i) returns node i's slot; leaf(start, end) tests the
+// leaf's items against the ray and returns true to abandon the traversal
+// (used by shadow rays only); tcur() is the current info.t the slab tests
+// compare against (bih.h:247-248 pass `info`).  `undo` points at this lane's
+// column: undo[level * kBlock].
+template <class LoadNode, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverse(LoadNode loadNode, uint32_t maxDepth, const SlabArgs &sa, const SlabBox &root,
+                                            float *undo, Leaf leaf, TCur tcur)
+{
+	uint32_t idx = 0, level = 0, pending = 0;
+	uint64_t axes = 0; // 2 bits per level: split axis of the path node at that level
+	vec3 nearT = root.nearT, farT = root.farT;
+
+	for (;;) {
+		const uint4 n = loadNode(idx);
+		// a node on the last level has no children in the heap (bih.h:131-134)
+		const bool isLeaf = (n.w & kNodeLeafBit) != 0 || level + 1 >= maxDepth;
+		if (!isLeaf) {
+			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
+			const bool sg = sa.sign(axis);
+			// lBB.max[axis] = left, rBB.min[axis] = right (bih.h:244-245)
+			const float tl = sa.plane(axis, asF(n.x));
+			const float tr = sa.plane(axis, asF(n.y));
+			// max is the far plane when the direction is positive, else the near plane
+			const vec3 lNear = sg ? withComp(nearT, axis, tl) : nearT;
+			const vec3 lFar = sg ? farT : withComp(farT, axis, tl);
+			const vec3 rNear = sg ? nearT : withComp(nearT, axis, tr);
+			const vec3 rFar = sg ? withComp(farT, axis, tr) : farT;
+			const float tc = tcur();
+			const bool hitL = slabTest(lNear, lFar, tc);
+			const bool hitR = slabTest(rNear, rFar, tc);
+			if (hitL || hitR) {
+				// left first; a right child that also hit waits (bih.h:253-264)
+				if (hitL && hitR) pending |= 1u << level;
+				const bool replacedNear = hitL ? sg : !sg;
+				undo[level * kBlock] = replacedNear ? nearT[int(axis)] : farT[int(axis)];
+				axes = (axes & ~(3ull << (2 * level))) | (uint64_t(axis) << (2 * level));
+				nearT = hitL ? lNear : rNear;
+				farT = hitL ? lFar : rFar;
+				idx = 2 * idx + (hitL ? 1 : 2);
+				level++;
+				continue;
+			}
+		} else {
+			const uint32_t start = n.z, end = n.w & kNodeEndMask;
+			if (leaf(start, end))
+				return;
+		}
+		// pop: deepest level whose right child is still pending
+		if (pending == 0)
+			return;
+		const uint32_t l = 31u - uint32_t(__clz(int(pending)));
+		pending &= ~(1u << l);
+		while (level > l) {
+			const bool wasLeft = (idx & 1u) != 0;
+			idx = (idx - 1) >> 1;
+			level--;
+			const uint32_t a = uint32_t(axes >> (2 * level)) & 3u;
+			const bool sg = sa.sign(a);
+			const float v = undo[level * kBlock];
+			const bool replacedNear = wasLeft ? sg : !sg;
+			if (replacedNear) nearT = withComp(nearT, a, v);
+			else farT = withComp(farT, a, v);
+		}
+		{
+			const uint4 pn = loadNode(idx);
+			const uint32_t a = (pn.w >> kNodeAxisShift) & 3u;
+			const bool sg = sa.sign(a);
+			const float tr = sa.plane(a, asF(pn.y));
+			// min is the near plane when the direction is positive
+			undo[level * kBlock] = sg ? farT[int(a)] : nearT[int(a)];
+			if (sg) farT = withComp(farT, a, tr);
+			else nearT = withComp(nearT, a, tr);
+			idx = 2 * idx + 2;
+			level++;
+		}
+	}
+}
+
+// HitInfo (geometry.h:22-27) for the world-space query, plus the primitive id
+struct WorldHit
+{
+	float t;
+	vec3 position, normal;
+	uint32_t material, prim;
+};
+
+// closest hit inside one object, in the object's local space (tmpInfo of scene.cu:418-424)
+struct LocalHit
+{
+	float t;
+	vec3 bary;
+	uint32_t tri; // slot index of the triangle record
+	uint32_t material;
+};
+
+template <class Mem>
+__device__ __forceinline__ mat4 loadMat4(const Mem &mem, uint32_t slot)
+{
+	mat4 m;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const uint4 q = mem.small(slot + j);
+		m.c[j] = vec4(asF(q.x), asF(q.y), asF(q.z), asF(q.w));
+	}
+	return m;
+}
+template <class Mem>
+__device__ __forceinline__ mat3 loadMat3(const Mem &mem, uint32_t slot, uint32_t &w9, uint32_t &w10)
+{
+	const uint4 q0 = mem.small(slot), q1 = mem.small(slot + 1), q2 = mem.small(slot + 2);
+	mat3 m;
+	m.c[0] = vec3(asF(q0.x), asF(q0.y), asF(q0.z));
+	m.c[1] = vec3(asF(q0.w), asF(q1.x), asF(q1.y));
+	m.c[2] = vec3(asF(q1.z), asF(q1.w), asF(q2.x));
+	w9 = q2.y;
+	w10 = q2.z;
+	return m;
+}
+
+// Mesh::intersect (geometry.cu:52-61) for a local-space ray
+template <class Mem>
+__device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, uint32_t meshId, const Ray &lr,
+                                              const SlabArgs &sa, LocalHit &tmp, float *undo)
+{
+	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
+	const uint4 q0 = mem.small(ms), q1 = mem.small(ms + 1), q2 = mem.small(ms + 2);
+	SlabBox root;
+	root.init(sa, vec3(asF(q0.x), asF(q0.y), asF(q0.z)), vec3(asF(q1.x), asF(q1.y), asF(q1.z)));
+	// boundingBox.intersect(r, info): the BIH root box is this same box (geometry.cu:47)
+	if (!slabTest(root.nearT, root.farT, tmp.t))
+		return false;
+	const uint32_t nodeBase = sc.off_mnodes + q1.w;
+	const uint32_t triBase = sc.off_tris + q2.x * kTriSlots;
+	bool intersected = false;
+	bihTraverse(
+		[&](uint32_t i) { return mem.large(nodeBase + i); }, q2.y, sa, root, undo,
+		[&](uint32_t start, uint32_t end) {
+			for (uint32_t i = start; i < end; i++) {
+				// Face::intersect (geometry.h:123-146)
+				const uint32_t ts = triBase + i * kTriSlots;
+				const uint4 t0 = mem.large(ts), t1 = mem.large(ts + 1), t2 = mem.large(ts + 2);
+				const vec3 a(asF(t0.x), asF(t0.y), asF(t0.z));
+				const vec3 e1(asF(t0.w), asF(t1.x), asF(t1.y));
+				const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
+				vec3 b;
+				float t;
+				if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t) && t < tmp.t) {
+					tmp.t = t;
+					tmp.bary = b;
+					tmp.tri = i + q2.x;
+					intersected = true;
+				}
+			}
+			return false;
+		},
+		[&]() { return tmp.t; });
+	if (intersected) {
+		tmp.material = q0.w;
+		return true;
+	}
+	return false;
+}
+
+// Object::intersect (scene.cu:407-440).  FULL = false skips what a shadow ray
+// never reads (normal, primitive id); info.t is computed identically.
+template <bool FULL, class Mem>
+__device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, WorldHit &info, float *undoMesh)
+{
+	const uint32_t os = sc.off_objects + obj * kObjectSlots;
+	Ray lr;
+	uint32_t meshBegin, meshCount;
+	{
+		const mat4 invM = loadMat4(mem, os);
+		const mat3 invN = loadMat3(mem, os + 4, meshBegin, meshCount);
+		lr.o = translate(invM, r.o);
+		lr.d = translaten(invN, r.d);
+	}
+	SlabArgs sa;
+	sa.init(lr);
+
+	bool intersected = false;
+	LocalHit tmp;
+	tmp.t = FLT_MAX;
+	tmp.tri = 0;
+	tmp.material = 0;
+	tmp.bary = vec3(0, 0, 0);
+	for (uint32_t k = 0; k < meshCount; k++) {
+		const uint32_t idSlot = sc.off_objmesh + ((meshBegin + k) >> 2);
+		const uint4 ids = mem.small(idSlot);
+		const uint32_t sel = (meshBegin + k) & 3u;
+		const uint32_t meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
+		intersected |= meshIntersect(mem, sc, meshId, lr, sa, tmp, undoMesh);
+	}
+
+	if (intersected) {
+		// info.point.position = r.o + r.d * t in local space (geometry.h:140), then to world (scene.cu:428)
+		const vec3 pl = lr.o + lr.d * tmp.t;
+		const mat4 M = loadMat4(mem, os + 7);
+		const vec3 pw = translate(M, pl);
+		const float t = length(pw - r.o);
+		if (t < info.t) {
+			info.t = t;
+			if constexpr (FULL) {
+				info.position = pw;
+				info.material = tmp.material;
+				const uint32_t ns = sc.off_normals + tmp.tri * kNormalSlots;
+				const uint4 n0 = mem.large(ns), n1 = mem.large(ns + 1), n2 = mem.large(ns + 2);
+				const vec3 na(asF(n0.x), asF(n0.y), asF(n0.z));
+				const vec3 nb(asF(n0.w), asF(n1.x), asF(n1.y));
+				const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
+				const vec3 nl = tmp.bary.x * na + tmp.bary.y * nb + tmp.bary.z * nc; // geometry.h:141
+				uint32_t u0, u1;
+				const mat3 N = loadMat3(mem, os + 11, u0, u1);
+				info.normal = translaten(N, nl); // scene.cu:429
+				info.prim = mem.large(sc.off_tris + tmp.tri * kTriSlots + 2).y;
+			}
+		}
+	}
+	return intersected;
+}
+
+// Scene::intersect (scene.cu:204-207): BIH<Object> traversal in world space.
+//
+// SHADOW: the callers at scene.cu:226,266 only ask whether
+// `info.t + eps < t` after the traversal, with info.t preset to t.  info.t
+// only ever decreases, and x -> x + eps is monotonic in binary32, so as soon
+// as one object leaves info.t + eps < t the answer is fixed: the remaining
+// objects can be skipped without changing it.  (The boolean `intersected` the
+// reference also tests is implied: info.t can only drop below t through a
+// hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
+template <bool SHADOW, class Mem>
+__device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
+                                               float *undoScene, float *undoMesh)
+{
+	SlabArgs sa;
+	sa.init(r);
+	SlabBox root;
+	root.init(sa, vec3(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), vec3(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]));
+	bool intersected = false;
+	bool occluded = false;
+	bihTraverse(
+		[&](uint32_t i) { return mem.small(sc.off_snodes + i); }, sc.scene_depth, sa, root, undoScene,
+		[&](uint32_t start, uint32_t end) {
+			for (uint32_t i = start; i < end; i++) {
+				intersected |= objectIntersect<!SHADOW>(mem, sc, i, r, info, undoMesh);
+				if constexpr (SHADOW) {
+					if (info.t + epsilon() < lightT) {
+						occluded = true;
+						return true;
+					}
+				}
+			}
+			return false;
+		},
+		[&]() { return info.t; });
+	return SHADOW ? occluded : intersected;
+}
+
+struct Light
+{
+	uint32_t type;
+	vec3 position, direction, diffuse;
+	float attConstant, attLinear, attQuadratic, innerCone, outerCone;
+};
+template <class Mem>
+__device__ __forceinline__ Light loadLight(const Mem &mem, const SceneHeader &sc, uint32_t i)
+{
+	const uint32_t s = sc.off_lights + i * kLightSlots;
+	const uint4 a = mem.small(s), b = mem.small(s + 1), c = mem.small(s + 2), d = mem.small(s + 3);
+	Light l;
+	l.position = vec3(asF(a.x), asF(a.y), asF(a.z));
+	l.type = a.w;
+	l.direction = vec3(asF(b.x), asF(b.y), asF(b.z));
+	l.attConstant = asF(b.w);
+	l.diffuse = vec3(asF(c.x), asF(c.y), asF(c.z));
+	l.attLinear = asF(c.w);
+	l.attQuadratic = asF(d.x);
+	l.innerCone = asF(d.y);
+	l.outerCone = asF(d.z);
+	return l;
+}
+
+struct Counters
+{
+	uint32_t shadow, bounce, primaryHits;
+};
+
+// Scene::lightPoint (scene.cu:273-292) with pointLightAccum (209-231) and spotLightAccum (234-271)
+template <class Mem>
+__device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc, const vec3 &pos, const vec3 &norm, RandState &state,
+                                           Counters &cnt, float *undoScene, float *undoMesh)
+{
+	vec3 light(0, 0, 0);
+	for (uint32_t i = 0; i < sc.num_lights; i++) {
+		const Light l = loadLight(mem, sc, i);
+		vec3 dir, c;
+		float t;
+		bool trace = true;
+		if (l.type == 0u) {
+			dir = (l.position + 0.5f * randNorm(state)) - pos;
+			t = length(dir);
+			dir = normalize(dir);
+			const float cosTheta = max(dot(dir, norm), 0.0f);
+			c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * t) * t) * l.diffuse;
+			if (length(c) < epsilon()) trace = false;
+		} else {
+			dir = l.position - pos;
+			t = length(dir);
+			dir = normalize(dir);
+			const float cosTheta = max(dot(dir, norm), 0.0f);
+			const float cosLight = dot(-dir, normalize(l.direction));
+			const float lightTheta = acosf(cosLight);
+			const float inner = l.outerCone - 1.57079632679f;
+			const float outer = l.innerCone;
+			const float falloff_distance = outer - inner;
+			if (fabsf(lightTheta) >= outer / 2.0f) {
+				c = vec3(0, 0, 0);
+				trace = false;
+			} else {
+				c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * t) * t) * l.diffuse;
+				if (length(c) < epsilon()) {
+					trace = false;
+				} else {
+					const float val = (outer / 2.0f - fabsf(lightTheta));
+					const float falloff = val / (falloff_distance / 2.0f);
+					if (double(fabsf(lightTheta)) >= double(inner) / 2.0)
+						c *= falloff;
+				}
+			}
+		}
+		if (trace) {
+			Ray sr;
+			sr.o = pos;
+			sr.d = dir;
+			WorldHit sh;
+			sh.t = t;
+			cnt.shadow++;
+			if (sceneIntersect<true>(mem, sc, sr, sh, t, undoScene, undoMesh))
+				c = vec3(0, 0, 0);
+		}
+		light += c;
+	}
+	return light;
+}
+
+// get_pixel_dir (renderer.cu:184-206)
+__device__ __forceinline__ vec3 getPixelDir(const RenderParams &p, float ni, float nj)
+{
+	const vec3 dir(p.cam_forward[0], p.cam_forward[1], p.cam_forward[2]);
+	const vec3 up(p.cam_up[0], p.cam_up[1], p.cam_up[2]);
+	const float AR = p.cam_aspect;
+	const vec3 cR = cross(dir, up);
+	const vec3 cU = cross(cR, dir);
+	const float dist = fastertanfull(p.cam_hfov / 2.0f);
+	return normalize(dir + dist * (nj * cU + AR * ni * cR));
+}
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// Copies blob slots [0, n) into LDS at the same offsets, 16 B per lane per step.
+__device__ __forceinline__ void stageScene(const uint4 *__restrict__ g, uint32_t n)
+{
+	for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+		g_lds[i] = g[i];
+	__syncthreads();
+}
+
+// scatterTrace (renderer.cu:326-388) with rayColor<N> (renderer.cu:232-324) unrolled into a loop.
+template <bool SMALL_LDS, bool LARGE_LDS>
+__global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
+{
+	const SceneHeader &sc = p.scene;
+	SceneMem<SMALL_LDS, LARGE_LDS> mem;
+	mem.g = p.blob;
+	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
+	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
+
+	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
+	float *undoScene = ldsF + threadIdx.x;
+	float *undoMesh = undoScene + sc.scene_depth * kBlock;
+	float *cstack = undoMesh + sc.max_mesh_depth * kBlock;
+
+	// which pixel slot: 16x16 pixels per workgroup, 8x8 per wave
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3), ly = (lane >> 3) + ((wave >> 1) << 3);
+	uint32_t oldx, oldy;
+	size_t outSlot;
+	bool tiled = p.num_tiles != 0;
+	if (tiled) {
+		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
+		const uint32_t tileNo = blockIdx.x / bpt, sub = blockIdx.x % bpt;
+		const uint32_t tile = p.tile_ids[tileNo];
+		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
+		oldx = (tile % p.tiles_x) * p.tile_w + inx;
+		oldy = (tile / p.tiles_x) * p.tile_h + iny;
+		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
+	} else {
+		oldx = (blockIdx.x % p.blocks_x) * 16u + lx;
+		oldy = (blockIdx.x / p.blocks_x) * 16u + ly;
+		outSlot = 0;
+	}
+
+	Counters cnt = {0, 0, 0};
+	const bool active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
+	if (active) {
+		const int width = int(p.width), height = int(p.height);
+		const int oldIndex = int(oldx) + width * int(oldy);
+		int index;
+		if (p.frames == 0) { // renderer.cu:344-352
+			if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
+			index = oldIndex;
+		} else {
+			index = p.pixel_values ? p.pixel_values[oldIndex] : oldIndex;
+		}
+		const int x = index % width;
+		const int y = index / width;
+		if (!tiled) outSlot = size_t(index);
+
+		RandState state;
+		randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
+
+		const float dx = 1.0f / width;
+		const float dy = 1.0f / height;
+		const float i = 2.0f * (float(x) + randUniform(state)) * dx - 1.0f;
+		const float j = 2.0f * (float(y) + randUniform(state)) * dy - 1.0f;
+
+		Ray r;
+		r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+		r.d = getPixelDir(p, i, -j);
+
+		// rayColor<max_bounces>(r, Color3(1,1,1), ...)
+		vec3 source(1, 1, 1);
+		vec4 tail(0, 0, 0, 1);
+		uint32_t level = 0;
+		uint32_t primId = 0xFFFFFFFFu;
+		float primT = FLT_MAX;
+		for (;;) {
+			if (level == p.max_bounces) // rayColor<0> (renderer.cu:318-324)
+				break;
+			WorldHit info;
+			info.t = FLT_MAX;
+			info.material = 0;
+			info.prim = 0xFFFFFFFFu;
+			info.position = vec3(0, 0, 0);
+			info.normal = vec3(0, 0, 0);
+			if (level > 0) cnt.bounce++;
+			if (!sceneIntersect<false>(mem, sc, r, info, 0.0f, undoScene, undoMesh))
+				break; // renderer.cu:315
+			if (level == 0) {
+				primId = info.prim;
+				primT = info.t;
+				cnt.primaryHits++;
+			}
+			const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
+			const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
+			const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
+			const float refractiveIndex = asF(m0.w);
+			const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
+			const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
+
+			// direct illum (renderer.cu:247-248)
+			const vec3 c = ambient + diffuse * lightPoint(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh);
+
+			// indirect illum.  nSource is uninitialised in the reference's
+			// translucent branch (renderer.cu:251,286-311); defined as `source` here.
+			vec3 nSource = source;
+			Ray nr;
+			nr.o = info.position;
+			nr.d = vec3(0, 0, 0);
+			const bool last = level + 1 == p.max_bounces; // the next level returns (0,0,0,1) whatever the ray
+			if (refractiveIndex == 0) {
+				const vec3 cd = source * diffuse;
+				const vec3 cs = source * specular;
+				const float Pd = compMax(cd) / compMax(source);
+				const float Ps = compMax(cs) / compMax(source);
+				const float P = randUniform(state);
+				if (P < Pd) {
+					if (!last) {
+						nSource = cd * (1 / Pd);
+						nr.d = randomHemi(info.normal, state);
+					}
+				} else if (P < Pd + Ps) {
+					if (!last) {
+						nSource = cs * (1 / Ps);
+						nr.d = reflect(r.d, info.normal);
+					}
+				} else {
+					tail = vec4(c, 1); // absorbed (renderer.cu:282)
+					break;
+				}
+			} else if (!last) {
+				float n1, n2;
+				vec3 norm = info.normal;
+				if (dot(r.d, norm) < 0) {
+					n1 = refractiveIndex;
+					n2 = 1;
+				} else {
+					n1 = 1;
+					n2 = refractiveIndex;
+					norm *= -1.0f;
+				}
+				const float R = rSchlick2(r.d, norm, n1, n2);
+				if (randUniform(state) >= R)
+					nr.d = refract(r.d, norm, n1 / n2);
+				else
+					nr.d = reflect(r.d, norm);
+			}
+			// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
+			cstack[(3 * level + 0) * kBlock] = c.x;
+			cstack[(3 * level + 1) * kBlock] = c.y;
+			cstack[(3 * level + 2) * kBlock] = c.z;
+			level++;
+			r = nr;
+			source = nSource;
+		}
+		vec4 contribution = tail;
+		while (level > 0) {
+			level--;
+			const vec4 cl(cstack[(3 * level + 0) * kBlock], cstack[(3 * level + 1) * kBlock], cstack[(3 * level + 2) * kBlock], 1.0f);
+			contribution = cl + contribution;
+		}
+
+		// average (renderer.cu:375-387)
+		float4 *px = p.screen + outSlot;
+		if (p.frames > 0) {
+			const float4 old = *px;
+			vec4 s(old.x, old.y, old.z, old.w);
+			s = s * (float(p.frames) / float(p.frames + 1));
+			s = s + (contribution / float(p.frames + 1));
+			*px = make_float4(s.x, s.y, s.z, s.w);
+		} else {
+			*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
+		}
+		if (p.primid) p.primid[outSlot] = primId;
+		if (p.hit_t) p.hit_t[outSlot] = primT;
+	}
+
+	if (p.counters) {
+		const uint32_t act = waveSum(active ? 1u : 0u);
+		const uint32_t sh = waveSum(cnt.shadow), bo = waveSum(cnt.bounce), ph = waveSum(cnt.primaryHits);
+		if (lane == 0) {
+			atomicAdd(&p.counters[0], (unsigned long long)act);
+			atomicAdd(&p.counters[1], (unsigned long long)sh);
+			atomicAdd(&p.counters[2], (unsigned long long)bo);
+			atomicAdd(&p.counters[3], (unsigned long long)ph);
+		}
+	}
+}
+
+// Scene::intersect for caller-supplied rays, one ray per work-item.
+template <bool SMALL_LDS, bool LARGE_LDS>
+__global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
+{
+	const SceneHeader &sc = p.scene;
+	SceneMem<SMALL_LDS, LARGE_LDS> mem;
+	mem.g = p.blob;
+	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
+	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
+	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
+	float *undoScene = ldsF + threadIdx.x;
+	float *undoMesh = undoScene + sc.scene_depth * kBlock;
+
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= p.n) return;
+	Ray r;
+	r.o = vec3(p.origins[3 * i], p.origins[3 * i + 1], p.origins[3 * i + 2]);
+	r.d = vec3(p.dirs[3 * i], p.dirs[3 * i + 1], p.dirs[3 * i + 2]);
+	WorldHit info;
+	info.t = p.tmax ? p.tmax[i] : FLT_MAX;
+	info.material = 0;
+	info.prim = 0xFFFFFFFFu;
+	info.position = vec3(0, 0, 0);
+	info.normal = vec3(0, 0, 0);
+	const bool h = sceneIntersect<false>(mem, sc, r, info, 0.0f, undoScene, undoMesh);
+	p.hit[i] = h ? 1 : 0;
+	p.t[i] = info.t;
+	p.prim[i] = info.prim;
+	p.position[3 * i] = info.position.x; p.position[3 * i + 1] = info.position.y; p.position[3 * i + 2] = info.position.z;
+	p.normal[3 * i] = info.normal.x; p.normal[3 * i + 1] = info.normal.y; p.normal[3 * i + 2] = info.normal.z;
+}
+
+// compact tiles -> full frame (last step of the multi-GPU gather)
+__global__ void __launch_bounds__(kBlock) scatterTilesKernel(const float4 *__restrict__ tiles, const uint32_t *__restrict__ tileIds,
+                                                             uint32_t tileW, uint32_t tileH, uint32_t tilesX, uint32_t width, uint32_t height,
+                                                             float4 *__restrict__ frame)
+{
+	const uint32_t tileNo = blockIdx.x;
+	const uint32_t tile = tileIds[tileNo];
+	const uint32_t x0 = (tile % tilesX) * tileW, y0 = (tile / tilesX) * tileH;
+	const uint32_t npx = tileW * tileH;
+	for (uint32_t k = threadIdx.x; k < npx; k += kBlock) {
+		const uint32_t x = x0 + k % tileW, y = y0 + k / tileW;
+		if (x < width && y < height)
+			frame[size_t(y) * width + x] = tiles[size_t(tileNo) * npx + k];
+	}
+}
+
+} // namespace dev
+} // namespace acr
+
+// ---- launchers used by the C ABI implementation (acr_hip.cpp) --------------
+
+extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+{
+	using namespace acr::dev;
+	void (*k)(const RenderParams) = ldsMode == 2 ? renderKernel<true, true> : (ldsMode == 1 ? renderKernel<true, false> : renderKernel<false, false>);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), ldsBytes, stream, *p);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+{
+	using namespace acr::dev;
+	void (*k)(const TraceParams) = ldsMode == 2 ? traceKernel<true, true> : (ldsMode == 1 ? traceKernel<true, false> : traceKernel<false, false>);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), ldsBytes, stream, *p);
+	return hipGetLastError();
+}
+
+extern "C" hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
+                                                   uint32_t width, uint32_t height, void *frame, hipStream_t stream)
+{
+	using namespace acr::dev;
+	const uint32_t tilesX = (width + tileW - 1) / tileW;
+	hipLaunchKernelGGL(scatterTilesKernel, dim3(numTiles), dim3(kBlock), 0, stream, static_cast<const float4 *>(tiles), tileIdsDev, tileW, tileH,
+	                   tilesX, width, height, static_cast<float4 *>(frame));
+	return hipGetLastError();
+}

@@ -1,0 +1,58 @@
+// Device-side scene image: one contiguous blob of 16-byte slots in HBM that a
+// workgroup can also stage into LDS wholesale.  Built from acr_scene_soa by
+// acr_hip_upload_scene, read by the kernels in acr_kernels.hip.
+//
+// Record formats (one uint4 = one slot; f = float bits, u = uint32):
+//   BIH node   1 slot : { f left, f right, u start, u end | axis<<28 | leaf<<30 }   (bih.h:92-98)
+//   object    14 slots: [0..3]  globalInverseTransform columns
+//                       [4..6]  globalInverseNormalTransform (9 f), u mesh_begin, u mesh_count, 0
+//                       [7..10] globalTransform columns
+//                       [11..13] globalNormalTransform (9 f), 0, 0, 0
+//   mesh       3 slots: { f min.xyz, u material } { f max.xyz, u node_begin } { u tri_begin, u depth, 0, 0 }
+//   triangle   3 slots: { a.x a.y a.z e1.x } { e1.y e1.z e2.x e2.y } { e2.z, u prim_id, 0, 0 }
+//                       with a = p0, e1 = p1 - p0, e2 = p2 - p0 (math.h:132-133)
+//   normals    3 slots: { n0.x n0.y n0.z n1.x } { n1.y n1.z n2.x n2.y } { n2.z 0 0 0 }
+//   material   3 slots: { ambient.xyz, f refractiveIndex } { diffuse.xyz, 0 } { specular.xyz, 0 }
+//   light      4 slots: { position.xyz, u type } { direction.xyz, f attConstant }
+//                       { diffuse.xyz, f attLinear } { f attQuadratic, f innerCone, f outerCone, 0 }
+//   obj->mesh id list : packed uint32, 4 per slot
+//
+// Section order: the small tables first (scene nodes, objects, id list,
+// meshes, materials, lights), then the large ones (mesh nodes, triangles,
+// normals), so "stage the small tables" and "stage everything" are both a
+// copy of a prefix.
+#ifndef ACR_DEVICE_SCENE_H
+#define ACR_DEVICE_SCENE_H
+
+#include <stdint.h>
+
+namespace acr
+{
+namespace dev
+{
+	constexpr uint32_t kNodeLeafBit = 1u << 30;
+	constexpr uint32_t kNodeAxisShift = 28;
+	constexpr uint32_t kNodeEndMask = (1u << 28) - 1;
+
+	constexpr uint32_t kObjectSlots = 14;
+	constexpr uint32_t kMeshSlots = 3;
+	constexpr uint32_t kTriSlots = 3;
+	constexpr uint32_t kNormalSlots = 3;
+	constexpr uint32_t kMaterialSlots = 3;
+	constexpr uint32_t kLightSlots = 4;
+
+	struct SceneHeader
+	{
+		// slot offsets of each section inside the blob
+		uint32_t off_snodes, off_objects, off_objmesh, off_meshes, off_materials, off_lights;
+		uint32_t off_mnodes, off_tris, off_normals;
+		uint32_t small_slots;   // slots [0, small_slots) hold the small tables
+		uint32_t total_slots;
+		uint32_t scene_depth, max_mesh_depth;
+		uint32_t num_objects, num_meshes, num_materials, num_lights, num_triangles;
+		float scene_min[3], scene_max[3];
+	};
+} // namespace dev
+} // namespace acr
+
+#endif

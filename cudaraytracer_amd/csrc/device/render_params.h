@@ -1,0 +1,62 @@
+// Kernel argument blocks, shared by the kernels (acr_kernels.hip) and the C ABI
+// implementation that fills them (acr_hip.cpp).  Passed by value: they take
+// the place of the reference's `__constant__ DevParams` (renderer.cu:14-23).
+#ifndef ACR_RENDER_PARAMS_H
+#define ACR_RENDER_PARAMS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+
+namespace acr
+{
+namespace dev
+{
+	struct RenderParams
+	{
+		SceneHeader scene;
+		const uint4 *blob;
+		// camera (camera.h:14-16), aspect already set to width/height (renderer.cu:179)
+		float cam_aspect, cam_hfov;
+		float cam_position[3], cam_forward[3], cam_up[3];
+		// frame
+		uint32_t width, height;
+		uint32_t blocks_x;          // ceil(width / 16), full-frame mode
+		uint64_t seed, frames;
+		uint32_t max_bounces;
+		// tile-list mode (num_tiles > 0)
+		uint32_t tile_w, tile_h, tiles_x, num_tiles;
+		const uint32_t *tile_ids;   // device
+		// buffers
+		int32_t *pixel_values;      // device or null
+		float4 *screen;
+		uint32_t *primid;           // device or null
+		float *hit_t;               // device or null
+		unsigned long long *counters; // device [4] or null: pixels, shadow rays, bounce rays, primary hits
+		uint32_t lds_stack_slot;    // first LDS slot after the staged scene
+	};
+
+	struct TraceParams
+	{
+		SceneHeader scene;
+		const uint4 *blob;
+		uint32_t n;
+		const float *origins, *dirs, *tmax;
+		uint8_t *hit;
+		float *t;
+		uint32_t *prim;
+		float *position, *normal;
+		uint32_t lds_stack_slot;
+	};
+} // namespace dev
+} // namespace acr
+
+extern "C" {
+hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream);
+hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream);
+hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
+                                        uint32_t width, uint32_t height, void *frame, hipStream_t stream);
+}
+
+#endif

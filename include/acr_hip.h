@@ -1,0 +1,216 @@
+/*
+ * acr_hip.h -- C ABI of the MI355X renderer core (libacr_hip.so).
+ *
+ * This is the drop-in boundary for the reference's one host->device crossing:
+ * the `scatterTrace<<<grid,block>>>(screen, seed, frames)` launch and the
+ * `__constant__ DevParams` / `acr::vector<T>` uploads that feed it
+ * (reference src/renderer/renderer.cu:14-23,168-182,326-327,417-422;
+ * src/utils/vector.h:46-55).  Everything below the boundary -- ray
+ * generation, BIH traversal, triangle tests, shading -- runs in hand-written
+ * HIP kernels for gfx950; everything above it (scene loading, BIH build,
+ * camera handling) stays host C++.
+ *
+ * Plain C: opaque context, plain pointers and sizes, int status codes
+ * (0 = ok).  No call exits the process; acr_hip_last_error() gives the text
+ * of the last failure on a context.  A context is bound to one GPU and is
+ * not thread-safe: the caller serialises calls on it, like the reference's
+ * single GLUT thread (renderer.cu:25-29).
+ *
+ * All "file:line" citations are relative to the reference checkout's root.
+ */
+#ifndef ACR_HIP_H
+#define ACR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACR_OK                 0
+#define ACR_ERR_INVALID        1   /* bad argument / inconsistent scene description */
+#define ACR_ERR_HIP            2   /* a HIP runtime call failed; see acr_hip_last_error */
+#define ACR_ERR_NO_SCENE       3   /* render before acr_hip_upload_scene / acr_hip_set_camera */
+#define ACR_ERR_UNSUPPORTED    4   /* e.g. BIH depth or bounce count beyond the compiled limits */
+
+#define ACR_MAX_BIH_DEPTH      30  /* node and item counts must stay below 2^28 */
+#define ACR_MAX_BOUNCES        16
+
+#define ACR_LIGHT_POINT        0   /* scene.h:58-63 */
+#define ACR_LIGHT_DIRECTIONAL  1
+#define ACR_LIGHT_SPOT         2
+
+#define ACR_NODE_AXIS_MASK     0x3u  /* node flag byte: bits 0-1 axis, bit 2 isLeaf (bih.h:96-97) */
+#define ACR_NODE_LEAF          0x4u
+
+#define ACR_PRIM_NONE          0xFFFFFFFFu
+
+typedef struct acr_hip_ctx acr_hip_ctx;
+
+/*
+ * Device-ready scene, structure-of-arrays.  Replaces the byte image of
+ * `acr::Scene` in DevParams (renderer.cu:16,171) and the device arrays the
+ * reference's acr::vector constructors upload (scene.cu:82-83,98,151;
+ * geometry.cu:37,47; bih.h:79).  All pointers are HOST pointers; the call
+ * copies what it needs.  Matrices are column-major, m[col*R + row], the glm
+ * layout the reference stores.
+ *
+ * BIH node arrays are the reference's implicit heap (children of i are 2i+1,
+ * 2i+2; bih.h:105-115), (1 << depth) - 1 entries, fields as in bih.h:92-98.
+ * Fields the reference's sift() leaves indeterminate (bih.h:139-143 and
+ * nodes it never reaches) may hold anything; the kernels never read them.
+ */
+typedef struct acr_scene_soa {
+	/* BIH over objects: Scene::objects, BIH<Object> (scene.h:117) */
+	uint32_t scene_depth;
+	float scene_min[3], scene_max[3];          /* Scene::boundingBox (scene.cu:145-149) */
+	const uint32_t *snode_start, *snode_end;
+	const float *snode_left, *snode_right;
+	const uint8_t *snode_flags;
+
+	/* objects in BIH order (after sift's permutation) */
+	uint32_t num_objects;
+	const float *obj_transform;                /* 16 each: globalTransform               (scene.cu:364) */
+	const float *obj_inv_transform;            /* 16 each: globalInverseTransform        (scene.cu:365) */
+	const float *obj_normal_transform;         /*  9 each: globalNormalTransform         (scene.cu:366) */
+	const float *obj_inv_normal_transform;     /*  9 each: globalInverseNormalTransform  (scene.cu:367) */
+	const uint32_t *obj_mesh_begin;            /* into obj_mesh_ids */
+	const uint32_t *obj_mesh_count;            /* Object::meshes.size() (scene.cu:404) */
+	uint32_t num_obj_mesh_ids;
+	const uint32_t *obj_mesh_ids;
+
+	/* meshes: acr::Mesh (mesh.h:11-33) */
+	uint32_t num_meshes;
+	const float *mesh_min, *mesh_max;          /* 3 each: Mesh::boundingBox (geometry.cu:31-32), also the BIH root box (geometry.cu:47) */
+	const uint32_t *mesh_material;             /* Mesh::materialIndex */
+	const uint32_t *mesh_depth;                /* MAX_DEPTH of this mesh's BIH<Face> */
+	const uint32_t *mesh_node_begin;           /* first node of this mesh in the mnode_* pools */
+	const uint32_t *mesh_tri_begin;            /* first triangle of this mesh in tri_*; node start/end are mesh-local */
+	uint32_t num_mesh_nodes;
+	const uint32_t *mnode_start, *mnode_end;
+	const float *mnode_left, *mnode_right;
+	const uint8_t *mnode_flags;
+
+	/* triangles in per-mesh BIH order, vertex data pre-gathered through
+	 * Face::indices (geometry.h:126-133): 3 floats per triangle per array */
+	uint32_t num_triangles;
+	const float *tri_p0, *tri_p1, *tri_p2;     /* Vertex::position of indices[0..2] */
+	const float *tri_n0, *tri_n1, *tri_n2;     /* Vertex::normal   of indices[0..2] */
+	const uint32_t *tri_prim_id;               /* caller-defined primitive id reported per pixel */
+
+	/* materials: acr::Material (materials.h:12-18) */
+	uint32_t num_materials;
+	const float *mat_ambient, *mat_diffuse, *mat_specular;   /* 3 each */
+	const float *mat_refractive_index;
+
+	/* lights: acr::Light (scene.h:52-80) after the node transform (scene.cu:174-183) */
+	uint32_t num_lights;
+	const int32_t *light_type;
+	const float *light_diffuse, *light_position, *light_direction;   /* 3 each */
+	const float *light_attenuation;            /* 3 each: constant, linear, quadratic */
+	const float *light_cone;                   /* 2 each: innerConeAngle, outerConeAngle */
+} acr_scene_soa;
+
+/* acr::Camera (camera.h:9-17).  aspect_ratio is overridden by width/height at
+ * render time, as Renderer::loadScene does (renderer.cu:179). */
+typedef struct acr_camera {
+	float aspect_ratio;
+	float horizontal_fov;
+	float position[3], forward[3], up[3];
+} acr_camera;
+
+/* One launch of the path (renderer.cu:417-423). */
+typedef struct acr_frame {
+	uint32_t width, height;        /* DevParams::width/height (renderer.cu:172-173) */
+	uint64_t seed;                 /* scatterTrace's `seed`: rand() in the reference (renderer.cu:421), explicit here */
+	uint64_t frames;               /* scatterTrace's `frames` = framesNoMove: 0 overwrites, >0 running mean (renderer.cu:375-387) */
+	uint32_t max_bounces;          /* MAX_BOUNCES (renderer.cu:10); reference value 5 */
+	/* Optional tile list for multi-GPU partitioning: when num_tiles > 0 only
+	 * those tiles are rendered and `screen` is the compact buffer
+	 * [num_tiles][tile_h][tile_w] float4.  Tile t covers pixels
+	 * x in [ (t % tiles_x) * tile_w, +tile_w ), y likewise with t / tiles_x,
+	 * tiles_x = ceil(width / tile_w).  num_tiles == 0 renders the whole frame
+	 * into [height][width] float4. */
+	uint32_t tile_w, tile_h;
+	uint32_t num_tiles;
+	const uint32_t *tile_ids;      /* host pointer */
+	/* Optional pixel permutation, DevParams::pixelValues (renderer.cu:19,343-355):
+	 * device pointer to width*height ints or NULL for identity.  Reset to
+	 * identity by the kernel when frames == 0, as in the reference. */
+	int32_t *pixel_values_dev;
+	uint32_t collect_stats;        /* nonzero: count rays and time the kernel (acr_hip_read_stats) */
+} acr_frame;
+
+typedef struct acr_stats {
+	uint64_t rays_primary, rays_shadow, rays_bounce;   /* rays actually traced by the last render */
+	uint64_t primary_hits;
+	float kernel_ms;               /* HIP-event time of the render kernel on the context's stream */
+	uint32_t lds_bytes;            /* dynamic LDS per workgroup of the last launch */
+	uint32_t scene_in_lds;         /* 2 whole scene staged in LDS, 1 only the small tables, 0 none */
+	uint32_t grid_blocks;
+} acr_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Binds a context to GPU `device_ordinal` and creates its stream.
+ * Replaces the device selection in Renderer::Renderer (renderer.cu:73-104). */
+int acr_hip_create(int device_ordinal, acr_hip_ctx **out);
+void acr_hip_destroy(acr_hip_ctx *ctx);
+const char *acr_hip_last_error(const acr_hip_ctx *ctx);
+
+/* Use an existing hipStream_t (e.g. the caller framework's current stream)
+ * for every later launch and copy; NULL restores the context's own stream. */
+int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream);
+int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at renderer.cu:422 */
+
+/* ---- scene, camera, buffers -------------------------------------------- */
+
+/* Validates and uploads the scene (replaces the acr::vector uploads and the
+ * Scene part of cudaMemcpyToSymbol, renderer.cu:171,181). */
+int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *scene);
+
+/* Camera part of DevParams: written by Renderer::loadScene / moveCamera
+ * (renderer.cu:163,181), read back by moveCamera (renderer.cu:148). */
+int acr_hip_set_camera(acr_hip_ctx *ctx, const acr_camera *camera);
+int acr_hip_get_camera(const acr_hip_ctx *ctx, acr_camera *camera);
+
+/* Allocates the context-owned framebuffer (W*H float4, the reference's PBO,
+ * renderer.cu:111), primitive-id / hit-distance buffers and the pixel map
+ * (renderer.cu:133,137). */
+int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height);
+
+/* ---- the hot path ------------------------------------------------------- */
+
+/* Launches the render kernel for one frame (renderer.cu:417-421) on the
+ * context's stream and returns without waiting.
+ *   screen_dev : device float4 buffer (see acr_frame); NULL = context-owned
+ *   primid_dev : optional device uint32 per pixel slot, primitive id of the
+ *                primary hit or ACR_PRIM_NONE; NULL = context-owned if sized
+ *   hit_t_dev  : optional device float per pixel slot, world-space t of the
+ *                primary hit (scene.cu:431) or FLT_MAX; NULL = context-owned */
+int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *frame, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev);
+
+/* Closest-hit queries for caller-supplied rays: Scene::intersect (scene.cu:204-207)
+ * with info.t preset to tmax[i].  Host arrays in and out; synchronous. */
+int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const float *dirs, const float *tmax,
+                       uint8_t *hit, float *t, uint32_t *prim, float *position, float *normal);
+
+/* ---- results (synchronous copies to host memory) ------------------------ */
+int acr_hip_read_framebuffer(acr_hip_ctx *ctx, float *rgba, size_t num_floats);
+int acr_hip_read_primid(acr_hip_ctx *ctx, uint32_t *prim, size_t count);
+int acr_hip_read_hit_t(acr_hip_ctx *ctx, float *t, size_t count);
+int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats);
+/* device address of the context-owned framebuffer (NULL before acr_hip_resize) */
+void *acr_hip_framebuffer(acr_hip_ctx *ctx);
+
+/* Copies compact tiles (as written by a tiled acr_hip_render) into a full
+ * [height][width] float4 frame on the same device: the last step after the
+ * finished tiles of every GPU have been gathered to GPU 0. */
+int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_t *tile_ids, uint32_t num_tiles,
+                          uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, void *frame_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACR_HIP_H */
