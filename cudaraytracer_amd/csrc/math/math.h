@@ -24,7 +24,14 @@ namespace acr
 {
 namespace math
 {
-	struct vec2 { float x, y; };
+	struct vec2
+	{
+		float x, y;
+		ACR_HD vec2() : x(0), y(0) {}
+		ACR_HD vec2(float a, float b) : x(a), y(b) {}
+	};
+	struct u32vec2 { uint32_t x, y; };
+	struct u32vec3 { uint32_t x, y, z; };
 
 	struct vec3
 	{

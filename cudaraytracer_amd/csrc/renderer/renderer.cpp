@@ -1,0 +1,140 @@
+#include "renderer.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+
+namespace acr
+{
+	void Renderer::check(int rc, const char *what)
+	{
+		if (rc != ACR_OK)
+			throw std::runtime_error(std::string(what) + ": " + (ctx ? acr_hip_last_error(ctx) : "no context") + " (code " + std::to_string(rc) + ")");
+	}
+
+	// renderer.cu:31-138 without the window, GL objects and pixel-key arrays
+	Renderer::Renderer(const Renderer::Args &args) : title(args.title), dim(args.dim), framesNoMove(0)
+	{
+		dim.x *= dim.z;
+		dim.y *= dim.z;
+		dim.z = 1;
+		const int rc = acr_hip_create(args.device, &ctx);
+		if (rc != ACR_OK)
+			throw std::runtime_error("acr_hip_create failed: no usable GPU " + std::to_string(args.device)); // renderer.cu:77-104 exits here
+		check(acr_hip_resize(ctx, dim.x, dim.y), "acr_hip_resize");
+	}
+
+	Renderer::~Renderer() { acr_hip_destroy(ctx); }
+
+	// renderer.cu:168-182
+	void Renderer::loadScene(const Scene &scene)
+	{
+		check(acr_hip_upload_scene(ctx, &scene.flatten()), "acr_hip_upload_scene");
+		Camera cam = scene.camera;
+		cam.aspectRatio = float(dim.x) / float(dim.y);
+		setCamera(cam);
+	}
+
+	void Renderer::setCamera(const Camera &cam)
+	{
+		acr_camera c{};
+		c.aspect_ratio = cam.aspectRatio;
+		c.horizontal_fov = cam.horizontalFOV;
+		const math::vec3 *src[3] = {&cam.position, &cam.forward, &cam.up};
+		float *dst[3] = {c.position, c.forward, c.up};
+		for (int k = 0; k < 3; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+		check(acr_hip_set_camera(ctx, &c), "acr_hip_set_camera");
+		framesNoMove = 0;
+	}
+
+	Camera Renderer::getCamera() const
+	{
+		acr_camera c{};
+		if (acr_hip_get_camera(ctx, &c) != ACR_OK) throw std::runtime_error("no camera set");
+		Camera cam;
+		cam.aspectRatio = c.aspect_ratio;
+		cam.horizontalFOV = c.horizontal_fov;
+		cam.position = math::vec3(c.position[0], c.position[1], c.position[2]);
+		cam.forward = math::vec3(c.forward[0], c.forward[1], c.forward[2]);
+		cam.up = math::vec3(c.up[0], c.up[1], c.up[2]);
+		return cam;
+	}
+
+	// renderer.cu:145-166: yaw about up, pitch about right, then translate; accumulation restarts
+	void Renderer::moveCamera(const math::vec2 &pos, const math::vec2 &dir)
+	{
+		Camera cam = getCamera();
+		cam.forward = math::rotate(cam.forward, dir.x, cam.up);
+		const math::vec3 right = math::cross(cam.forward, cam.up);
+		cam.forward = math::rotate(cam.forward, dir.y, right);
+		cam.up = math::rotate(cam.up, dir.y, right);
+		const math::vec3 delta = cam.forward * pos.y + right * pos.x;
+		cam.position += delta;
+		setCamera(cam);
+	}
+
+	// renderer.cu:397-423
+	void Renderer::render()
+	{
+		acr_frame f{};
+		f.width = dim.x;
+		f.height = dim.y;
+		f.seed = fixedSeed >= 0 ? uint64_t(fixedSeed) + framesNoMove : uint64_t(rand());
+		f.frames = framesNoMove;
+		f.max_bounces = maxBounces;
+		f.collect_stats = collectStats ? 1u : 0u;
+		check(acr_hip_render(ctx, &f, nullptr, nullptr, nullptr), "acr_hip_render");
+		check(acr_hip_sync(ctx), "acr_hip_sync"); // cudaDeviceSynchronize (renderer.cu:422)
+		framesNoMove++;
+	}
+
+	void Renderer::readFramebuffer(std::vector<float> &rgba)
+	{
+		rgba.resize(size_t(dim.x) * dim.y * 4);
+		check(acr_hip_read_framebuffer(ctx, rgba.data(), rgba.size()), "acr_hip_read_framebuffer");
+	}
+	void Renderer::readPrimitiveIds(std::vector<uint32_t> &ids)
+	{
+		ids.resize(size_t(dim.x) * dim.y);
+		check(acr_hip_read_primid(ctx, ids.data(), ids.size()), "acr_hip_read_primid");
+	}
+	void Renderer::readHitDistances(std::vector<float> &t)
+	{
+		t.resize(size_t(dim.x) * dim.y);
+		check(acr_hip_read_hit_t(ctx, t.data(), t.size()), "acr_hip_read_hit_t");
+	}
+	acr_stats Renderer::stats()
+	{
+		acr_stats s{};
+		check(acr_hip_read_stats(ctx, &s), "acr_hip_read_stats");
+		return s;
+	}
+
+	void Renderer::save(const std::string &path)
+	{
+		std::vector<float> rgba;
+		readFramebuffer(rgba);
+		FILE *fp = std::fopen(path.c_str(), "wb");
+		if (!fp) throw std::runtime_error("cannot write " + path);
+		const bool pfm = path.size() > 4 && path.substr(path.size() - 4) == ".pfm";
+		if (pfm) {
+			// PFM stores rows bottom-up; image row 0 is the top row here
+			std::fprintf(fp, "PF\n%u %u\n-1.0\n", dim.x, dim.y);
+			for (uint32_t y = dim.y; y-- > 0;)
+				for (uint32_t x = 0; x < dim.x; x++)
+					std::fwrite(&rgba[4 * (size_t(y) * dim.x + x)], 4, 3, fp);
+		} else {
+			std::fprintf(fp, "P6\n%u %u\n255\n", dim.x, dim.y);
+			for (size_t i = 0; i < size_t(dim.x) * dim.y; i++) {
+				unsigned char px[3];
+				for (int k = 0; k < 3; k++) {
+					float v = rgba[4 * i + k];
+					v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+					px[k] = (unsigned char)(v * 255.0f + 0.5f);
+				}
+				std::fwrite(px, 1, 3, fp);
+			}
+		}
+		std::fclose(fp);
+	}
+} // namespace acr
