@@ -87,7 +87,7 @@ class Frame(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("seed", C.c_uint64), ("frames", C.c_uint64),
                 ("max_bounces", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("num_tiles", C.c_uint32), ("tile_ids", c_u32_p), ("pixel_values_dev", C.c_void_p),
-                ("collect_stats", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("tile_rays_dev", C.c_void_p), ("tile_cycles_dev", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -138,6 +138,7 @@ HOST_SYMBOLS = {
     "acr_host_renderer_error": (C.c_char_p, [C.c_void_p]),
     "acr_host_renderer_load_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "acr_host_renderer_move_camera": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "acr_host_move_camera": (C.c_int, [C.POINTER(Camera), c_float_p, c_float_p]),
     "acr_host_renderer_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_host_renderer_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_host_renderer_configure": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32]),

@@ -151,7 +151,8 @@ class HipCore:
         self._w, self._hh = w, h
 
     def render(self, width, height, seed=0, frames=0, max_bounces=1, collect_stats=False, screen_dev=None,
-               primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None):
+               primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None,
+               tile_rays_dev=None, tile_cycles_dev=None):
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
         f.collect_stats = 1 if collect_stats else 0
@@ -161,6 +162,8 @@ class HipCore:
             f.tile_w, f.tile_h, f.num_tiles = tile_w, tile_h, len(keep)
             f.tile_ids = keep.ctypes.data_as(_capi.c_u32_p)
         f.pixel_values_dev = pixel_values_dev
+        f.tile_rays_dev = tile_rays_dev
+        f.tile_cycles_dev = tile_cycles_dev
         self._check(self._lib.acr_hip_render(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render")
 
     def sync(self):

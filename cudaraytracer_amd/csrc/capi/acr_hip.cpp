@@ -390,6 +390,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		if (g >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "too many tiles");
 		grid = uint32_t(g);
 	} else {
+		if (f->tile_rays_dev || f->tile_cycles_dev) return fail(ctx, ACR_ERR_INVALID, "per-tile costs need a tile list");
 		grid = ((f->width + 15) / 16) * ((f->height + 15) / 16);
 	}
 
@@ -432,6 +433,10 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
 	p.hit_t = hit_t_dev ? hit_t_dev : (ownBuffers ? ctx->hitT : nullptr);
 	p.counters = f->collect_stats ? ctx->counters : nullptr;
+	p.tile_rays = f->tile_rays_dev;
+	p.tile_cycles = f->tile_cycles_dev;
+	if (p.tile_rays) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_rays, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
+	if (p.tile_cycles) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_cycles, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 
 	const LaunchPlan plan = planLds(ctx->header, f->max_bounces ? f->max_bounces : 1);
 	p.lds_stack_slot = plan.stackSlot;

@@ -255,6 +255,22 @@ int acr_host_renderer_get_camera(const acr_host_renderer *r, acr_camera *cam)
 	}
 }
 
+int acr_host_move_camera(acr_camera *cam, const float pos[2], const float dir[2])
+{
+	if (!cam || !pos || !dir) return ACR_ERR_INVALID;
+	Camera c;
+	c.aspectRatio = cam->aspect_ratio;
+	c.horizontalFOV = cam->horizontal_fov;
+	c.position = math::vec3(cam->position[0], cam->position[1], cam->position[2]);
+	c.forward = math::vec3(cam->forward[0], cam->forward[1], cam->forward[2]);
+	c.up = math::vec3(cam->up[0], cam->up[1], cam->up[2]);
+	c = movedCamera(c, math::vec2(pos[0], pos[1]), math::vec2(dir[0], dir[1]));
+	cam->position[0] = c.position.x; cam->position[1] = c.position.y; cam->position[2] = c.position.z;
+	cam->forward[0] = c.forward.x; cam->forward[1] = c.forward.y; cam->forward[2] = c.forward.z;
+	cam->up[0] = c.up.x; cam->up[1] = c.up.y; cam->up[2] = c.up.z;
+	return ACR_OK;
+}
+
 int acr_host_renderer_configure(acr_host_renderer *r, uint32_t max_bounces, int64_t fixed_seed, uint32_t collect_stats)
 {
 	return guarded(r, [&] {

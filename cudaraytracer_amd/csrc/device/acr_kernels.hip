@@ -522,11 +522,14 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 	const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3), ly = (lane >> 3) + ((wave >> 1) << 3);
 	uint32_t oldx, oldy;
 	size_t outSlot;
-	bool tiled = p.num_tiles != 0;
+	uint32_t tileNoOfBlock = 0;
+	const bool tiled = p.num_tiles != 0;
+	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
 	if (tiled) {
 		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
 		const uint32_t tileNo = blockIdx.x / bpt, sub = blockIdx.x % bpt;
 		const uint32_t tile = p.tile_ids[tileNo];
+		tileNoOfBlock = tileNo;
 		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
 		oldx = (tile % p.tiles_x) * p.tile_w + inx;
 		oldy = (tile / p.tiles_x) * p.tile_h + iny;
@@ -672,6 +675,14 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 		if (p.hit_t) p.hit_t[outSlot] = primT;
 	}
 
+	if (tiled && (p.tile_rays || p.tile_cycles)) {
+		if (p.tile_rays) {
+			const uint32_t rays = waveSum((active ? 1u : 0u) + cnt.shadow + cnt.bounce);
+			if (lane == 0) atomicAdd(&p.tile_rays[tileNoOfBlock], rays);
+		}
+		if (p.tile_cycles && lane == 0)
+			atomicAdd(&p.tile_cycles[tileNoOfBlock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	}
 	if (p.counters) {
 		const uint32_t act = waveSum(active ? 1u : 0u);
 		const uint32_t sh = waveSum(cnt.shadow), bo = waveSum(cnt.bounce), ph = waveSum(cnt.primaryHits);

@@ -60,17 +60,23 @@ namespace acr
 		return cam;
 	}
 
-	// renderer.cu:145-166: yaw about up, pitch about right, then translate; accumulation restarts
-	void Renderer::moveCamera(const math::vec2 &pos, const math::vec2 &dir)
+	// renderer.cu:152-161: yaw about up, pitch about right, then translate
+	Camera movedCamera(const Camera &camera, const math::vec2 &pos, const math::vec2 &dir)
 	{
-		Camera cam = getCamera();
+		Camera cam = camera;
 		cam.forward = math::rotate(cam.forward, dir.x, cam.up);
 		const math::vec3 right = math::cross(cam.forward, cam.up);
 		cam.forward = math::rotate(cam.forward, dir.y, right);
 		cam.up = math::rotate(cam.up, dir.y, right);
 		const math::vec3 delta = cam.forward * pos.y + right * pos.x;
 		cam.position += delta;
-		setCamera(cam);
+		return cam;
+	}
+
+	// renderer.cu:145-166: read the camera back, move it, write it, restart accumulation
+	void Renderer::moveCamera(const math::vec2 &pos, const math::vec2 &dir)
+	{
+		setCamera(movedCamera(getCamera(), pos, dir));
 	}
 
 	// renderer.cu:397-423

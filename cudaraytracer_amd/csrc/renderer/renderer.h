@@ -18,6 +18,9 @@
 
 namespace acr
 {
+	// the camera arithmetic of Renderer::moveCamera (renderer.cu:152-161) on its own
+	Camera movedCamera(const Camera &camera, const math::vec2 &pos, const math::vec2 &dir);
+
 	class Renderer
 	{
 	public:

@@ -140,6 +140,15 @@ typedef struct acr_frame {
 	 * identity by the kernel when frames == 0, as in the reference. */
 	int32_t *pixel_values_dev;
 	uint32_t collect_stats;        /* nonzero: count rays and time the kernel (acr_hip_read_stats) */
+	/* Optional per-tile cost feedback for the next frame's tile assignment
+	 * (the measured counterpart of the reference's per-pixel path statistics,
+	 * renderer.cu:380,386,457-461): device uint32[num_tiles] each, zeroed by the
+	 * call and filled by the kernel, entry i for tile_ids[i].  tile_rays_dev
+	 * counts the rays traced for the tile (deterministic); tile_cycles_dev sums
+	 * the shader-clock cycles its wavefronts ran, divided by 64 (timing, varies
+	 * from run to run).  Either may be NULL.  Tile mode only. */
+	uint32_t *tile_rays_dev;
+	uint32_t *tile_cycles_dev;
 } acr_frame;
 
 typedef struct acr_stats {

@@ -118,6 +118,8 @@ void acr_host_renderer_destroy(acr_host_renderer *r);
 const char *acr_host_renderer_error(const acr_host_renderer *r);
 int acr_host_renderer_load_scene(acr_host_renderer *r, const acr_host_scene *scene);       /* renderer.cu:168-182 */
 int acr_host_renderer_move_camera(acr_host_renderer *r, const float pos[2], const float dir[2]); /* renderer.cu:145-166 */
+/* the camera arithmetic of moveCamera alone (renderer.cu:152-161), no GPU involved */
+int acr_host_move_camera(acr_camera *cam, const float pos[2], const float dir[2]);
 int acr_host_renderer_set_camera(acr_host_renderer *r, const acr_camera *cam);              /* direct placement; resets accumulation */
 int acr_host_renderer_get_camera(const acr_host_renderer *r, acr_camera *cam);
 /* MAX_BOUNCES (renderer.cu:10) and the rand() seed source (application.cpp:76, renderer.cu:421):

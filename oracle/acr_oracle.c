@@ -882,6 +882,7 @@ static int object_intersect(const object_t *o, const ray_t *r, hitinfo_t *info, 
 
 	if (intersected) {
 		float t;
+		st->c.object_hits++;
 		tmpInfo.point.position = translate_pt(&o->globalTransform, tmpInfo.point.position);
 		tmpInfo.point.normal = translaten(&o->globalNormalTransform, tmpInfo.point.normal);
 		t = length3(sub3(tmpInfo.point.position, r->o));
@@ -1322,6 +1323,7 @@ static void counters_add(orc_counters *a, const orc_counters *b)
 	a->rays_primary += b->rays_primary; a->rays_shadow += b->rays_shadow; a->rays_bounce += b->rays_bounce;
 	a->primary_hits += b->primary_hits; a->node_visits += b->node_visits; a->slab_tests += b->slab_tests;
 	a->object_visits += b->object_visits; a->mesh_visits += b->mesh_visits; a->triangle_tests += b->triangle_tests;
+	a->object_hits += b->object_hits;
 }
 
 int orc_render(const orc_scene *s, const orc_camera *cam_in, const orc_frame *f,

@@ -101,6 +101,7 @@ typedef struct orc_counters {
 	uint64_t object_visits;   /* Object::intersect calls */
 	uint64_t mesh_visits;     /* Mesh::intersect calls */
 	uint64_t triangle_tests;  /* Face::intersect calls */
+	uint64_t object_hits;     /* Object::intersect calls whose local ray hit something (scene.cu:426-437 runs) */
 } orc_counters;
 
 typedef struct orc_frame {

@@ -1,0 +1,114 @@
+"""The multi-GPU frame assembly, rehearsed with two CPU processes over gloo:
+each rank renders its tiles (the oracle stands in for the GPU core here),
+rank 0 gathers and assembles, and the result must equal one full-frame render.
+Covers the uniform split, cost feedback and a camera-move reset."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+W, H, TW, TH = 176, 100, 32, 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cudaraytracer_amd as acr
+    import oracle
+    from cudaraytracer_amd import distributed as D
+
+    data = acr.ImportData.load(os.path.join(HERE, "golden", "scenes", "cornell-box-cycles.json"))
+    view, keep = data.pack()
+    o = oracle.OracleScene(view)
+    state = dict(seed=21)
+    rendered = []
+
+    def render_tiles(tile_ids, out, cost):
+        # stand-in for the GPU core: render the frame on the CPU, cut out this rank's tiles
+        r = o.render(W, H, seed=state["seed"], frames=0, max_bounces=2, threads=2)
+        img = r["screen"]
+        tiles_x = (W + TW - 1) // TW
+        buf = np.zeros((len(tile_ids), TH, TW, 4), np.float32)
+        c = np.zeros(len(tile_ids), np.float32)
+        for k, t in enumerate(tile_ids):
+            x0, y0 = (int(t) % tiles_x) * TW, (int(t) // tiles_x) * TH
+            w, h = min(TW, W - x0), min(TH, H - y0)
+            buf[k, :h, :w] = img[y0:y0 + h, x0:x0 + w]
+            c[k] = 1.0 + float((r["prim"][y0:y0 + h, x0:x0 + w] != 0xFFFFFFFF).sum())
+        out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
+        cost.copy_(torch.from_numpy(c))
+        rendered.append(len(tile_ids))
+
+    dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
+    results = {}
+    splits = []
+    for step, seed in enumerate((21, 22, 23)):
+        state["seed"] = seed
+        if step == 2:
+            dr.camera_moved()  # back to the uniform split
+        splits.append([int(x) for x in dr.plan.begin])
+        frame = dr.render_frame()
+        if rank == 0:
+            ref = o.render(W, H, seed=seed, frames=0, max_bounces=2, threads=2)["screen"]
+            results[f"equal{step}"] = bool(np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32)))
+    if rank == 0:
+        results["splits"] = splits
+        results["rendered"] = rendered
+        torch.save(results, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_frame_assembly(tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    res = torch.load(out)
+    assert res["equal0"] and res["equal1"] and res["equal2"]
+    s0, s1, s2 = res["splits"]
+    n = s0[-1]
+    assert s0 == [0, n // 2, n] and s2 == s0          # uniform at start and after the camera move
+    assert s1 != s0 and s1[0] == 0 and s1[-1] == n    # rebalanced from the first frame's costs
+
+
+def test_single_rank_path_without_process_group():
+    """world size 1: no communication at all, same assembly code."""
+    sys.path.insert(0, HERE)
+    import cudaraytracer_amd as acr
+    import oracle
+    from cudaraytracer_amd import distributed as D
+    data = acr.ImportData.load(os.path.join(HERE, "golden", "scenes", "triangles.json"))
+    view, keep = data.pack()
+    o = oracle.OracleScene(view)
+    ref = o.render(W, H, seed=5, max_bounces=1)["screen"]
+    tiles_x = (W + TW - 1) // TW
+
+    def render_tiles(tile_ids, out, cost):
+        buf = np.zeros((len(tile_ids), TH, TW, 4), np.float32)
+        for k, t in enumerate(tile_ids):
+            x0, y0 = (int(t) % tiles_x) * TW, (int(t) // tiles_x) * TH
+            w, h = min(TW, W - x0), min(TH, H - y0)
+            buf[k, :h, :w] = ref[y0:y0 + h, x0:x0 + w]
+        out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
+        cost.fill_(1.0)
+
+    dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
+    frame = dr.render_frame()
+    assert np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32))

@@ -1,0 +1,262 @@
+"""GPU parity: the HIP path, called through the C ABI of include/acr_hip.h,
+against the CPU oracle on the same scenes, cameras and seeds.
+
+Bar: primitive ids, hit distances and RGBA all bit-exact (the radiance
+tolerance the task allows, 1e-4 relative, is not needed: both sides perform the
+same IEEE binary32 operations in the same order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import Built, soup_data
+
+pytestmark = pytest.mark.gpu
+
+FMAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def core(acr):
+    c = acr.HipCore(0)
+    yield c
+    c.close()
+
+
+def load(core, b):
+    core.upload_scene(b.scene.soa)
+    core.set_camera(b.scene.camera)
+
+
+def render(core, w, h, **kw):
+    core.resize(w, h)
+    core.render(w, h, collect_stats=True, **kw)
+    core.sync()
+    return core.read_framebuffer(), core.read_primid(), core.read_hit_t(), core.read_stats()
+
+
+def assert_same(img, pid, ht, st, ref):
+    assert np.array_equal(pid, ref["prim"])
+    assert np.array_equal(ht.view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(img.view(np.uint32), ref["screen"].view(np.uint32))
+    c = ref["counters"]
+    assert (st.rays_primary, st.rays_shadow, st.rays_bounce, st.primary_hits) == (
+        c["rays_primary"], c["rays_shadow"], c["rays_bounce"], c["primary_hits"])
+
+
+@pytest.mark.parametrize("name,w,h,bounces", [
+    ("triangles", 640, 480, 1),          # configuration 1 of the benchmark list
+    ("triangles", 33, 17, 5),            # ragged size: partial workgroups on both edges
+    ("plane", 320, 240, 1),
+    ("plane", 200, 120, 3),
+    ("cornell-box-cycles", 480, 270, 1),
+    ("cornell-box-cycles", 240, 136, 5),  # the reference's MAX_BOUNCES
+    ("cornell-box-cycles", 1, 1, 2),
+])
+def test_render_matches_oracle(core, built, name, w, h, bounces):
+    b = built[name]
+    load(core, b)
+    img, pid, ht, st = render(core, w, h, seed=7, frames=0, max_bounces=bounces)
+    assert st.scene_in_lds == 2  # these scenes are staged whole into LDS
+    assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=7, frames=0, max_bounces=bounces))
+
+
+def test_golden_vectors_on_gpu(core, built):
+    """the committed oracle vectors, so the GPU is also held to fixed data, not only to a live oracle"""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_renders.npz"))
+    for name in ("triangles", "plane", "cornell-box-cycles"):
+        load(core, built[name])
+        for bounces in (1, 5):
+            img, pid, ht, _ = render(core, 96, 72, seed=7, frames=0, max_bounces=bounces)
+            key = f"{name}/b{bounces}"
+            assert np.array_equal(pid, gold[key + "/prim"])
+            assert np.array_equal(ht.view(np.uint32), gold[key + "/t"])
+            assert np.array_equal(img.view(np.uint32), gold[key + "/rgba"])
+
+
+def test_cornell_1080p_full_size(core, built):
+    """configuration 2 at full size, every pixel compared"""
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    img, pid, ht, st = render(core, 1920, 1080, seed=12345, frames=0, max_bounces=1)
+    ref = b.oracle.render(1920, 1080, seed=12345, frames=0, max_bounces=1)
+    assert_same(img, pid, ht, st, ref)
+    mse = float(np.mean((img[..., :3].astype(np.float64) - ref["screen"][..., :3]) ** 2))
+    assert mse == 0.0  # PSNR is infinite
+    # size-independent properties
+    miss = pid == 0xFFFFFFFF
+    assert np.all(ht[miss] == FMAX) and np.all(img[miss][:, :3] == 0) and np.all(img[..., 3][miss] == 1)
+    assert np.isfinite(img).all() and pid[~miss].max() < 72
+    assert 0.54 < (~miss).mean() < 0.56
+
+
+def test_progressive_accumulation(core, built):
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 160, 90
+    core.resize(w, h)
+    screen = None
+    for f in range(6):
+        core.render(w, h, seed=100 + f, frames=f, max_bounces=2)
+        ref = b.oracle.render(w, h, seed=100 + f, frames=f, max_bounces=2, screen=screen)
+        screen = ref["screen"]
+    core.sync()
+    assert np.array_equal(core.read_framebuffer().view(np.uint32), screen.view(np.uint32))
+
+
+def test_tile_list_and_scatter(core, built, acr):
+    """tiles rendered out of order into a compact buffer, then scattered, equal the full frame;
+    per-tile ray counts add up to the oracle's total"""
+    import torch
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h, tw, th = 200, 120, 64, 16
+    tx, ty = (w + tw - 1) // tw, (h + th - 1) // th
+    ids = np.random.default_rng(1).permutation(tx * ty).astype(np.uint32)
+    halves = [ids[: len(ids) // 3], ids[len(ids) // 3:]]
+    frame = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    total_rays = 0
+    try:
+        for part in halves:
+            tiles = torch.zeros((len(part), th * tw, 4), dtype=torch.float32, device="cuda")
+            rays = torch.zeros(len(part), dtype=torch.int32, device="cuda")
+            cyc = torch.zeros(len(part), dtype=torch.int32, device="cuda")
+            core.render(w, h, seed=3, frames=0, max_bounces=2, tile_ids=part, tile_w=tw, tile_h=th,
+                        screen_dev=C.c_void_p(tiles.data_ptr()), tile_rays_dev=C.c_void_p(rays.data_ptr()),
+                        tile_cycles_dev=C.c_void_p(cyc.data_ptr()))
+            core.scatter_tiles(C.c_void_p(tiles.data_ptr()), part, tw, th, w, h, C.c_void_p(frame.data_ptr()))
+            core.sync()
+            total_rays += int(rays.sum().item())
+            assert int(cyc.min().item()) > 0
+    finally:
+        core.set_stream(None)
+    ref = b.oracle.render(w, h, seed=3, frames=0, max_bounces=2)
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref["screen"].view(np.uint32))
+    c = ref["counters"]
+    assert total_rays == c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+
+
+def test_pixel_permutation(core, built):
+    """DevParams::pixelValues: frame 0 resets the map to identity, later frames follow it"""
+    import torch
+    b = built["triangles"]
+    load(core, b)
+    w, h = 64, 48
+    core.resize(w, h)
+    pm = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    core.render(w, h, seed=9, frames=0, max_bounces=1, pixel_values_dev=C.c_void_p(pm.data_ptr()))
+    core.sync()
+    assert np.array_equal(pm.cpu().numpy(), np.arange(w * h, dtype=np.int32))
+    perm = np.random.default_rng(0).permutation(w * h).astype(np.int32)
+    pm.copy_(torch.from_numpy(perm))
+    torch.cuda.synchronize()
+    core.render(w, h, seed=4, frames=1, max_bounces=1, pixel_values_dev=C.c_void_p(pm.data_ptr()))
+    core.sync()
+    base = b.oracle.render(w, h, seed=9, frames=0, max_bounces=1)["screen"]
+    ref = b.oracle.render(w, h, seed=4, frames=1, max_bounces=1, screen=base, pixel_map=perm)["screen"]
+    assert np.array_equal(core.read_framebuffer().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["triangles", "plane", "cornell-box-cycles"])
+def test_trace_rays_matches_oracle(core, built, name):
+    """Scene::intersect for arbitrary rays, including directions with zero components (inf / NaN slab terms)"""
+    b = built[name]
+    load(core, b)
+    rng = np.random.default_rng(5)
+    n = 4096
+    mn, mx = b.oracle.bounds()
+    ctr, ext = (mn + mx) / 2, (mx - mn).max() + 1.0
+    org = (ctr + rng.uniform(-1, 1, (n, 3)) * ext).astype(np.float32)
+    tgt = (ctr + rng.uniform(-0.5, 0.5, (n, 3)) * (mx - mn)).astype(np.float32)
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    # axis-aligned and planar directions
+    d[:300] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1, 1], (300, 1)).astype(np.float32)
+    d[300:600, 1] = 0
+    tmax = np.full(n, FMAX, np.float32)
+    tmax[600:900] = rng.uniform(0.5, 6, 300).astype(np.float32)
+    g = core.trace_rays(org, d, tmax)
+    r = b.oracle.trace_rays(org, d, tmax)
+    assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"])
+    assert np.array_equal(g["t"].view(np.uint32), r["t"].view(np.uint32))
+    h = r["prim"] != 0xFFFFFFFF
+    assert np.array_equal(g["position"][h].view(np.uint32), r["position"][h].view(np.uint32))
+    assert np.array_equal(g["normal"][h].view(np.uint32), r["normal"][h].view(np.uint32))
+    assert h.sum() > 100
+
+
+@pytest.mark.parametrize("ntri,depth,mode", [(400, 6, 2), (3000, 10, 1), (60000, 14, 0)])
+def test_soup_deeper_bih_and_lds_modes(core, acr, orc, ntri, depth, mode):
+    """procedural soup at larger BIH depths: scene fully in LDS / only the small tables / nothing staged"""
+    b = Built(acr, orc, soup_data(acr, ntri, seed=4, edge=0.08), mesh_depth=depth)
+    load(core, b)
+    w, h = 192, 108
+    img, pid, ht, st = render(core, w, h, seed=11, frames=0, max_bounces=2)
+    if mode != 0:
+        assert st.scene_in_lds == mode
+    assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=11, frames=0, max_bounces=2))
+    assert (pid != 0xFFFFFFFF).mean() > 0.05
+
+
+def test_translucent_material_path(core, acr, orc, scene_data):
+    """refractiveIndex != 0 (renderer.cu:286-311), unused by the shipped scenes: glass cubes in plane.blend"""
+    import copy
+    d = copy.deepcopy(scene_data["plane"])
+    d.materials[d.meshes[0]["material"]]["refracti"] = 1.5
+    b = Built(acr, orc, d)
+    load(core, b)
+    img, pid, ht, st = render(core, 160, 120, seed=2, frames=0, max_bounces=5)
+    assert_same(img, pid, ht, st, b.oracle.render(160, 120, seed=2, frames=0, max_bounces=5))
+    assert st.rays_bounce > 0
+
+
+def test_empty_scene_and_no_lights(core, acr, orc, scene_data):
+    import copy
+    d = copy.deepcopy(scene_data["triangles"])
+    d.lights = []
+    b = Built(acr, orc, d)
+    load(core, b)
+    img, pid, ht, st = render(core, 64, 48, seed=1, frames=0, max_bounces=2)
+    assert_same(img, pid, ht, st, b.oracle.render(64, 48, seed=1, frames=0, max_bounces=2))
+    assert st.rays_shadow == 0
+    for n in d.nodes:
+        n["meshes"] = []
+    b2 = Built(acr, orc, d)
+    load(core, b2)
+    img, pid, ht, st = render(core, 64, 48, seed=1, frames=0, max_bounces=2)
+    assert np.all(pid == 0xFFFFFFFF) and np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
+
+
+def test_error_paths(acr, built):
+    c = acr.HipCore(0)
+    try:
+        with pytest.raises(RuntimeError, match="before scene"):
+            c.render(16, 16)
+        load(c, built["triangles"])
+        with pytest.raises(RuntimeError, match="resize"):
+            c.render(16, 16)  # no framebuffer yet
+        c.resize(16, 16)
+        with pytest.raises(RuntimeError, match="max_bounces"):
+            c.render(16, 16, max_bounces=17)
+        with pytest.raises(RuntimeError, match="multiples of 16"):
+            c.render(16, 16, tile_ids=np.array([0], np.uint32), tile_w=8, tile_h=8, screen_dev=C.c_void_p(c.framebuffer_ptr()))
+        with pytest.raises(RuntimeError, match="out of range"):
+            c.render(16, 16, tile_ids=np.array([5], np.uint32), tile_w=16, tile_h=16, screen_dev=C.c_void_p(c.framebuffer_ptr()))
+        # a corrupted BIH (internal node on the last level) is rejected at upload, not discovered by the kernel
+        s = built["triangles"].scene.soa
+        from cudaraytracer_amd import _capi
+        bad = _capi.SceneSoA()
+        C.memmove(C.byref(bad), C.byref(s), C.sizeof(s))
+        flags = np.zeros((1 << s.scene_depth) - 1, np.uint8)
+        bad.snode_flags = flags.ctypes.data_as(_capi.c_u8_p)
+        with pytest.raises(RuntimeError, match="last level"):
+            c.upload_scene(bad)
+        c.render(16, 16, max_bounces=1)  # the previous, valid scene is still loaded
+        c.sync()
+    finally:
+        c.close()
+    with pytest.raises(RuntimeError, match="no usable GPU"):
+        acr.HipCore(9999)
