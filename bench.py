@@ -80,7 +80,10 @@ def main():
     core = acr.HipCore(local_rank)
     core.upload_scene(scene.soa)
     core.set_camera(scene.camera)
-    core.set_stream(torch.cuda.current_stream().cuda_stream)  # so torch events and RCCL order against the kernel
+    # one explicit stream for kernels, torch events and RCCL ordering
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    core.set_stream(stream.cuda_stream)
 
     seed0 = 12345
     step_no = [0]

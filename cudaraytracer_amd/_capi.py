@@ -102,6 +102,7 @@ HIP_SYMBOLS = {
     "acr_hip_destroy": (None, [C.c_void_p]),
     "acr_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "acr_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "acr_hip_use_own_stream": (C.c_int, [C.c_void_p]),
     "acr_hip_sync": (C.c_int, [C.c_void_p]),
     "acr_hip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneSoA)]),
     "acr_hip_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),

@@ -144,7 +144,11 @@ class HipCore:
         self._check(self._lib.acr_hip_set_camera(self._h, C.byref(cam)), "acr_hip_set_camera")
 
     def set_stream(self, stream_ptr):
-        self._check(self._lib.acr_hip_set_stream(self._h, C.c_void_p(stream_ptr)), "acr_hip_set_stream")
+        """hipStream_t as an integer; 0 / None is HIP's default stream"""
+        self._check(self._lib.acr_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)), "acr_hip_set_stream")
+
+    def use_own_stream(self):
+        self._check(self._lib.acr_hip_use_own_stream(self._h), "acr_hip_use_own_stream")
 
     def resize(self, w, h):
         self._check(self._lib.acr_hip_resize(self._h, w, h), "acr_hip_resize")

@@ -46,7 +46,7 @@ struct acr_hip_ctx
 	int32_t *pixelValues = nullptr;
 
 	// per-launch scratch
-	unsigned long long *counters = nullptr; // device [4]
+	unsigned long long *counters = nullptr; // device [kCounterSlots][4]
 	uint32_t *tileIds = nullptr;            // device copy of the tile list
 	std::vector<uint32_t> tileIdsHost;      // stays alive while the async copy reads it
 	size_t tileIdsCap = 0;
@@ -59,6 +59,7 @@ struct acr_hip_ctx
 namespace
 {
 	constexpr uint32_t kBlock = 256;
+	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
 	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
 	constexpr size_t kLdsBudget = 64 * 1024;
 
@@ -158,7 +159,7 @@ int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
 	acr_hip_ctx *ctx = new acr_hip_ctx();
 	ctx->device = device_ordinal;
 	if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess ||
-	    hipMalloc(reinterpret_cast<void **>(&ctx->counters), 4 * sizeof(unsigned long long)) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->counters), kCounterSlots * 4 * sizeof(unsigned long long)) != hipSuccess ||
 	    hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess) {
 		acr_hip_destroy(ctx);
 		return ACR_ERR_HIP;
@@ -191,7 +192,14 @@ const char *acr_hip_last_error(const acr_hip_ctx *ctx) { return ctx ? ctx->error
 int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return ACR_ERR_INVALID;
-	ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+	ctx->stream = static_cast<hipStream_t>(hip_stream);
+	return ACR_OK;
+}
+
+int acr_hip_use_own_stream(acr_hip_ctx *ctx)
+{
+	if (!ctx) return ACR_ERR_INVALID;
+	ctx->stream = ctx->ownStream;
 	return ACR_OK;
 }
 
@@ -443,7 +451,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 
 	ctx->timed = f->collect_stats != 0;
 	if (ctx->timed) {
-		ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+		ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
 		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
 	}
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, grid, plan.ldsBytes, ctx->stream));
@@ -538,8 +546,10 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timed) {
+		unsigned long long slots[kCounterSlots * 4];
+		ACR_HIP_TRY(ctx, hipMemcpy(slots, ctx->counters, sizeof(slots), hipMemcpyDeviceToHost));
 		unsigned long long c[4] = {0, 0, 0, 0};
-		ACR_HIP_TRY(ctx, hipMemcpy(c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost));
+		for (uint32_t k = 0; k < kCounterSlots * 4; k++) c[k & 3] += slots[k];
 		ctx->stats.rays_primary = c[0];
 		ctx->stats.rays_shadow = c[1];
 		ctx->stats.rays_bounce = c[2];

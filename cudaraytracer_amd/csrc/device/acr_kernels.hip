@@ -687,10 +687,11 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 		const uint32_t act = waveSum(active ? 1u : 0u);
 		const uint32_t sh = waveSum(cnt.shadow), bo = waveSum(cnt.bounce), ph = waveSum(cnt.primaryHits);
 		if (lane == 0) {
-			atomicAdd(&p.counters[0], (unsigned long long)act);
-			atomicAdd(&p.counters[1], (unsigned long long)sh);
-			atomicAdd(&p.counters[2], (unsigned long long)bo);
-			atomicAdd(&p.counters[3], (unsigned long long)ph);
+			unsigned long long *slot = p.counters + 4 * (blockIdx.x % kCounterSlots);
+			atomicAdd(&slot[0], (unsigned long long)act);
+			atomicAdd(&slot[1], (unsigned long long)sh);
+			atomicAdd(&slot[2], (unsigned long long)bo);
+			atomicAdd(&slot[3], (unsigned long long)ph);
 		}
 	}
 }

@@ -41,6 +41,10 @@ namespace dev
 	constexpr uint32_t kMaterialSlots = 3;
 	constexpr uint32_t kLightSlots = 4;
 
+	// ray counters are spread over this many slots of 4 words so that the
+	// workgroups' atomic adds do not all land on one address
+	constexpr uint32_t kCounterSlots = 64;
+
 	struct SceneHeader
 	{
 		// slot offsets of each section inside the blob

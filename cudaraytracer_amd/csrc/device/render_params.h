@@ -33,7 +33,7 @@ namespace dev
 		float4 *screen;
 		uint32_t *primid;           // device or null
 		float *hit_t;               // device or null
-		unsigned long long *counters; // device [4] or null: pixels, shadow rays, bounce rays, primary hits
+		unsigned long long *counters; // device [kCounterSlots][4] or null: pixels, shadow rays, bounce rays, primary hits
 		uint32_t *tile_rays;          // device [num_tiles] or null
 		uint32_t *tile_cycles;        // device [num_tiles] or null
 		uint32_t lds_stack_slot;    // first LDS slot after the staged scene

@@ -169,8 +169,10 @@ void acr_hip_destroy(acr_hip_ctx *ctx);
 const char *acr_hip_last_error(const acr_hip_ctx *ctx);
 
 /* Use an existing hipStream_t (e.g. the caller framework's current stream)
- * for every later launch and copy; NULL restores the context's own stream. */
+ * for every later launch and copy.  NULL is HIP's default stream, as in any
+ * HIP call.  acr_hip_use_own_stream goes back to the context's own stream. */
 int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream);
+int acr_hip_use_own_stream(acr_hip_ctx *ctx);
 int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at renderer.cu:422 */
 
 /* ---- scene, camera, buffers -------------------------------------------- */

@@ -131,7 +131,7 @@ def test_tile_list_and_scatter(core, built, acr):
             total_rays += int(rays.sum().item())
             assert int(cyc.min().item()) > 0
     finally:
-        core.set_stream(None)
+        core.use_own_stream()
     ref = b.oracle.render(w, h, seed=3, frames=0, max_bounces=2)
     assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref["screen"].view(np.uint32))
     c = ref["counters"]
@@ -198,7 +198,7 @@ def test_soup_deeper_bih_and_lds_modes(core, acr, orc, ntri, depth, mode):
     if mode != 0:
         assert st.scene_in_lds == mode
     assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=11, frames=0, max_bounces=2))
-    assert (pid != 0xFFFFFFFF).mean() > 0.05
+    assert (pid != 0xFFFFFFFF).mean() > 0.01
 
 
 def test_translucent_material_path(core, acr, orc, scene_data):
