@@ -62,7 +62,8 @@ class SceneSoA(C.Structure):
         ("snode_flags", c_u8_p),
         ("num_objects", C.c_uint32),
         ("obj_transform", c_float_p), ("obj_inv_transform", c_float_p), ("obj_normal_transform", c_float_p),
-        ("obj_inv_normal_transform", c_float_p), ("obj_mesh_begin", c_u32_p), ("obj_mesh_count", c_u32_p),
+        ("obj_inv_normal_transform", c_float_p), ("obj_world_min", c_float_p), ("obj_world_max", c_float_p),
+        ("obj_mesh_begin", c_u32_p), ("obj_mesh_count", c_u32_p),
         ("num_obj_mesh_ids", C.c_uint32), ("obj_mesh_ids", c_u32_p),
         ("num_meshes", C.c_uint32), ("mesh_min", c_float_p), ("mesh_max", c_float_p), ("mesh_material", c_u32_p),
         ("mesh_depth", c_u32_p), ("mesh_node_begin", c_u32_p), ("mesh_tri_begin", c_u32_p),

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -90,14 +91,19 @@ namespace
 	// Walks the nodes reachable from the root and checks what the kernels rely on:
 	// an internal node has both children inside the heap, a leaf's item range is
 	// inside [0, itemCount].
-	bool checkBih(uint32_t depth, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t itemCount, std::string &why)
+	bool checkBih(uint32_t depth, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t itemCount, std::string &why,
+	              uint32_t *levelsUsed)
 	{
+		uint32_t deepest = 0;
 		if (depth < 1 || depth > ACR_MAX_BIH_DEPTH) { why = "BIH depth out of range"; return false; }
 		const uint64_t count = (1ull << depth) - 1;
 		std::vector<uint32_t> todo(1, 0u);
 		while (!todo.empty()) {
 			const uint32_t i = todo.back();
 			todo.pop_back();
+			uint32_t level = 0;
+			while ((2u << level) - 1 <= i) level++; // node i sits on level floor(log2(i + 1))
+			if (level > deepest) deepest = level;
 			if (flags[i] & ACR_NODE_LEAF) {
 				if (start[i] <= end[i] && end[i] > itemCount) { why = "leaf item range outside the item array"; return false; }
 				continue;
@@ -107,6 +113,7 @@ namespace
 			todo.push_back(2 * i + 2);
 			todo.push_back(2 * i + 1);
 		}
+		if (levelsUsed) *levelsUsed = deepest + 1;
 		return true;
 	}
 
@@ -219,7 +226,10 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "scene too large for 28-bit item indices");
 	if (!s->snode_start || !s->snode_end || !s->snode_left || !s->snode_right || !s->snode_flags)
 		return fail(ctx, ACR_ERR_INVALID, "scene BIH arrays missing");
-	if (!checkBih(s->scene_depth, s->snode_start, s->snode_end, s->snode_flags, s->num_objects, why))
+	// Only the levels a traversal can reach are packed: a tree built with MAX_DEPTH 6 over two
+	// triangles uses 2 of its 6 levels, and LDS space is what limits residency.
+	uint32_t sceneLevels = 1;
+	if (!checkBih(s->scene_depth, s->snode_start, s->snode_end, s->snode_flags, s->num_objects, why, &sceneLevels))
 		return fail(ctx, ACR_ERR_INVALID, "scene BIH: %s", why.c_str());
 	if (s->num_objects && (!s->obj_transform || !s->obj_inv_transform || !s->obj_normal_transform || !s->obj_inv_normal_transform ||
 	                       !s->obj_mesh_begin || !s->obj_mesh_count))
@@ -231,6 +241,8 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	for (uint32_t i = 0; i < s->num_obj_mesh_ids; i++)
 		if (s->obj_mesh_ids[i] >= s->num_meshes) return fail(ctx, ACR_ERR_INVALID, "obj_mesh_ids[%u] out of range", i);
 	uint32_t maxMeshDepth = 1;
+	std::vector<uint32_t> meshLevels(s->num_meshes, 1), meshNodeAt(s->num_meshes, 0);
+	uint32_t packedMeshNodes = 0;
 	for (uint32_t m = 0; m < s->num_meshes; m++) {
 		const uint32_t d = s->mesh_depth[m];
 		if (d < 1 || d > ACR_MAX_BIH_DEPTH) return fail(ctx, ACR_ERR_UNSUPPORTED, "mesh %u: BIH depth %u", m, d);
@@ -239,17 +251,19 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 		const uint32_t nb = s->mesh_node_begin[m];
 		const uint32_t triBegin = s->mesh_tri_begin[m];
 		if (triBegin > s->num_triangles) return fail(ctx, ACR_ERR_INVALID, "mesh %u: tri_begin out of range", m);
-		if (!checkBih(d, s->mnode_start + nb, s->mnode_end + nb, s->mnode_flags + nb, s->num_triangles - triBegin, why))
+		if (!checkBih(d, s->mnode_start + nb, s->mnode_end + nb, s->mnode_flags + nb, s->num_triangles - triBegin, why, &meshLevels[m]))
 			return fail(ctx, ACR_ERR_INVALID, "mesh %u BIH: %s", m, why.c_str());
 		if (s->mesh_material[m] >= s->num_materials) return fail(ctx, ACR_ERR_INVALID, "mesh %u: material index out of range", m);
-		if (d > maxMeshDepth) maxMeshDepth = d;
+		if (meshLevels[m] > maxMeshDepth) maxMeshDepth = meshLevels[m];
+		meshNodeAt[m] = packedMeshNodes;
+		packedMeshNodes += (1u << meshLevels[m]) - 1;
 	}
 	for (uint32_t i = 0; i < s->num_lights; i++)
 		if (s->light_type[i] < 0 || s->light_type[i] > 2) return fail(ctx, ACR_ERR_INVALID, "light %u: unknown type", i);
 
 	// ---- pack ----
 	SceneHeader h{};
-	const uint32_t snodeCount = (1u << s->scene_depth) - 1;
+	const uint32_t snodeCount = (1u << sceneLevels) - 1;
 	uint32_t at = 0;
 	h.off_snodes = at; at += snodeCount;
 	h.off_objects = at; at += s->num_objects * acr::dev::kObjectSlots;
@@ -258,11 +272,11 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	h.off_materials = at; at += s->num_materials * acr::dev::kMaterialSlots;
 	h.off_lights = at; at += s->num_lights * acr::dev::kLightSlots;
 	h.small_slots = at;
-	h.off_mnodes = at; at += s->num_mesh_nodes;
+	h.off_mnodes = at; at += packedMeshNodes;
 	h.off_tris = at; at += s->num_triangles * acr::dev::kTriSlots;
 	h.off_normals = at; at += s->num_triangles * acr::dev::kNormalSlots;
 	h.total_slots = at;
-	h.scene_depth = s->scene_depth;
+	h.scene_depth = sceneLevels;
 	h.max_mesh_depth = maxMeshDepth;
 	h.num_objects = s->num_objects;
 	h.num_meshes = s->num_meshes;
@@ -275,21 +289,57 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	std::vector<uint4> blob(h.total_slots ? h.total_slots : 1, make_uint4(0, 0, 0, 0));
 	for (uint32_t i = 0; i < snodeCount; i++)
 		putNode(blob[h.off_snodes + i], s->snode_left[i], s->snode_right[i], s->snode_start[i], s->snode_end[i], s->snode_flags[i]);
+	// margin of the conservative world boxes: three to four orders of magnitude above fp32 rounding at scene scale
+	double diag2 = 0;
+	for (int k = 0; k < 3; k++) diag2 += double(s->scene_max[k] - s->scene_min[k]) * double(s->scene_max[k] - s->scene_min[k]);
+	const float margin = std::isfinite(diag2) ? float(std::fmax(2e-3, 1e-3 * std::sqrt(diag2))) : 0.0f;
 	for (uint32_t i = 0; i < s->num_objects; i++) {
 		uint32_t *w = reinterpret_cast<uint32_t *>(&blob[h.off_objects + i * acr::dev::kObjectSlots]);
-		memcpy(w, s->obj_inv_transform + 16 * size_t(i), 64);
-		memcpy(w + 16, s->obj_inv_normal_transform + 9 * size_t(i), 36);
-		w[25] = s->obj_mesh_begin[i];
-		w[26] = s->obj_mesh_count[i];
-		memcpy(w + 28, s->obj_transform + 16 * size_t(i), 64);
-		memcpy(w + 44, s->obj_normal_transform + 9 * size_t(i), 36);
+		const float *M = s->obj_transform + 16 * size_t(i), *MI = s->obj_inv_transform + 16 * size_t(i);
+		uint32_t flags = 0;
+		auto affine = [](const float *m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; };
+		if (affine(MI)) flags |= acr::dev::kObjInvAffine;
+		if (affine(M)) flags |= acr::dev::kObjFwdAffine;
+		if (s->obj_world_min && s->obj_world_max && margin > 0.0f && affine(M) && affine(MI)) {
+			// the skip is only valid where the reference's local ray is the true image of the world ray:
+			// rotation times uniform scale (the direction goes through transpose(mat3(M)), scene.cu:366-367,413)
+			double g[3][3], tr = 0;
+			bool ok = true;
+			for (int a = 0; a < 3; a++)
+				for (int b = 0; b < 3; b++) {
+					g[a][b] = 0;
+					for (int k = 0; k < 3; k++) g[a][b] += double(M[4 * a + k]) * double(M[4 * b + k]);
+				}
+			tr = (g[0][0] + g[1][1] + g[2][2]) / 3.0;
+			ok = std::isfinite(tr) && tr > 0;
+			for (int a = 0; a < 3 && ok; a++)
+				for (int b = 0; b < 3 && ok; b++)
+					ok = std::fabs(g[a][b] - (a == b ? tr : 0.0)) <= 1e-4 * tr;
+			float mn[3], mx[3];
+			for (int k = 0; k < 3 && ok; k++) {
+				mn[k] = s->obj_world_min[3 * size_t(i) + k] - margin;
+				mx[k] = s->obj_world_max[3 * size_t(i) + k] + margin;
+				ok = std::isfinite(mn[k]) && std::isfinite(mx[k]) && mn[k] < mx[k];
+			}
+			if (ok) {
+				flags |= acr::dev::kObjPrefilter;
+				for (int k = 0; k < 3; k++) { w[k] = fbits(mn[k]); w[4 + k] = fbits(mx[k]); }
+			}
+		}
+		w[3] = flags;
+		memcpy(w + 8, MI, 64);
+		memcpy(w + 24, s->obj_inv_normal_transform + 9 * size_t(i), 36);
+		w[33] = s->obj_mesh_begin[i];
+		w[34] = s->obj_mesh_count[i];
+		memcpy(w + 36, M, 64);
+		memcpy(w + 52, s->obj_normal_transform + 9 * size_t(i), 36);
 	}
 	if (s->num_obj_mesh_ids) memcpy(&blob[h.off_objmesh], s->obj_mesh_ids, 4 * size_t(s->num_obj_mesh_ids));
 	for (uint32_t m = 0; m < s->num_meshes; m++) {
 		uint4 *q = &blob[h.off_meshes + m * acr::dev::kMeshSlots];
 		q[0] = make_uint4(fbits(s->mesh_min[3 * m]), fbits(s->mesh_min[3 * m + 1]), fbits(s->mesh_min[3 * m + 2]), s->mesh_material[m]);
-		q[1] = make_uint4(fbits(s->mesh_max[3 * m]), fbits(s->mesh_max[3 * m + 1]), fbits(s->mesh_max[3 * m + 2]), s->mesh_node_begin[m]);
-		q[2] = make_uint4(s->mesh_tri_begin[m], s->mesh_depth[m], 0, 0);
+		q[1] = make_uint4(fbits(s->mesh_max[3 * m]), fbits(s->mesh_max[3 * m + 1]), fbits(s->mesh_max[3 * m + 2]), meshNodeAt[m]);
+		q[2] = make_uint4(s->mesh_tri_begin[m], meshLevels[m], 0, 0);
 	}
 	for (uint32_t i = 0; i < s->num_materials; i++) {
 		uint4 *q = &blob[h.off_materials + i * acr::dev::kMaterialSlots];
@@ -306,8 +356,12 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 		q[2] = make_uint4(fbits(dif[0]), fbits(dif[1]), fbits(dif[2]), fbits(att[1]));
 		q[3] = make_uint4(fbits(att[2]), fbits(cone[0]), fbits(cone[1]), 0);
 	}
-	for (uint32_t i = 0; i < s->num_mesh_nodes; i++)
-		putNode(blob[h.off_mnodes + i], s->mnode_left[i], s->mnode_right[i], s->mnode_start[i], s->mnode_end[i], s->mnode_flags[i]);
+	for (uint32_t m = 0; m < s->num_meshes; m++) {
+		const uint32_t nb = s->mesh_node_begin[m], count = (1u << meshLevels[m]) - 1;
+		for (uint32_t i = 0; i < count; i++)
+			putNode(blob[h.off_mnodes + meshNodeAt[m] + i], s->mnode_left[nb + i], s->mnode_right[nb + i], s->mnode_start[nb + i],
+			        s->mnode_end[nb + i], s->mnode_flags[nb + i]);
+	}
 	for (uint32_t i = 0; i < s->num_triangles; i++) {
 		const float *a = s->tri_p0 + 3 * size_t(i), *b = s->tri_p1 + 3 * size_t(i), *c = s->tri_p2 + 3 * size_t(i);
 		// e1 = b - a, e2 = c - a: the two subtractions of math.h:132-133, done once here
@@ -446,7 +500,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	if (p.tile_rays) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_rays, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 	if (p.tile_cycles) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_cycles, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces ? f->max_bounces : 1);
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0);
 	p.lds_stack_slot = plan.stackSlot;
 
 	ctx->timed = f->collect_stats != 0;

@@ -294,16 +294,37 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 
 // Object::intersect (scene.cu:407-440).  FULL = false skips what a shadow ray
 // never reads (normal, primitive id); info.t is computed identically.
+//
+// Before the reference's work starts, the ray is tested against the object's
+// world-space box grown by a margin (device_scene.h, kObjPrefilter).  A ray
+// that misses the grown box misses the object's local mesh boxes by a distance
+// three to four orders of magnitude above fp32 rounding, so the reference's
+// own mesh box test (geometry.cu:55) would fail for every mesh and the call
+// would return false with `info` untouched: returning false here is the same
+// result without the two matrix transforms.  The test ignores info.t on
+// purpose (a box beyond the current hit must still report `intersected`).
+// The host sets the flag only for rotation * uniform scale transforms, where
+// the reference's local ray is the true image of the world ray.
 template <bool FULL, class Mem>
-__device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, WorldHit &info, float *undoMesh)
+__device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
+                                                WorldHit &info, float *undoMesh)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
+	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
+	const uint32_t flags = b0.w;
+	if (flags & kObjPrefilter) {
+		SlabBox wb;
+		wb.init(saWorld, vec3(asF(b0.x), asF(b0.y), asF(b0.z)), vec3(asF(b1.x), asF(b1.y), asF(b1.z)));
+		if (!slabTest(wb.nearT, wb.farT, FLT_MAX))
+			return false;
+	}
 	Ray lr;
 	uint32_t meshBegin, meshCount;
 	{
-		const mat4 invM = loadMat4(mem, os);
-		const mat3 invN = loadMat3(mem, os + 4, meshBegin, meshCount);
-		lr.o = translate(invM, r.o);
+		const mat4 invM = loadMat4(mem, os + 2);
+		const mat3 invN = loadMat3(mem, os + 6, meshBegin, meshCount);
+		// hom.w is exactly 1 for an affine matrix and x / 1 == x (math.h:174-178)
+		lr.o = (flags & kObjInvAffine) ? translateAffine(invM, r.o) : translate(invM, r.o);
 		lr.d = translaten(invN, r.d);
 	}
 	SlabArgs sa;
@@ -326,8 +347,8 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	if (intersected) {
 		// info.point.position = r.o + r.d * t in local space (geometry.h:140), then to world (scene.cu:428)
 		const vec3 pl = lr.o + lr.d * tmp.t;
-		const mat4 M = loadMat4(mem, os + 7);
-		const vec3 pw = translate(M, pl);
+		const mat4 M = loadMat4(mem, os + 9);
+		const vec3 pw = (flags & kObjFwdAffine) ? translateAffine(M, pl) : translate(M, pl);
 		const float t = length(pw - r.o);
 		if (t < info.t) {
 			info.t = t;
@@ -341,7 +362,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 				const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
 				const vec3 nl = tmp.bary.x * na + tmp.bary.y * nb + tmp.bary.z * nc; // geometry.h:141
 				uint32_t u0, u1;
-				const mat3 N = loadMat3(mem, os + 11, u0, u1);
+				const mat3 N = loadMat3(mem, os + 13, u0, u1);
 				info.normal = translaten(N, nl); // scene.cu:429
 				info.prim = mem.large(sc.off_tris + tmp.tri * kTriSlots + 2).y;
 			}
@@ -373,7 +394,7 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 		[&](uint32_t i) { return mem.small(sc.off_snodes + i); }, sc.scene_depth, sa, root, undoScene,
 		[&](uint32_t start, uint32_t end) {
 			for (uint32_t i = start; i < end; i++) {
-				intersected |= objectIntersect<!SHADOW>(mem, sc, i, r, info, undoMesh);
+				intersected |= objectIntersect<!SHADOW>(mem, sc, i, r, sa, info, undoMesh);
 				if constexpr (SHADOW) {
 					if (info.t + epsilon() < lightT) {
 						occluded = true;
@@ -644,6 +665,10 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 					nr.d = refract(r.d, norm, n1 / n2);
 				else
 					nr.d = reflect(r.d, norm);
+			}
+			if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
+				tail = vec4(c, 1) + vec4(0, 0, 0, 1);
+				break;
 			}
 			// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
 			cstack[(3 * level + 0) * kBlock] = c.x;

@@ -4,10 +4,12 @@
 //
 // Record formats (one uint4 = one slot; f = float bits, u = uint32):
 //   BIH node   1 slot : { f left, f right, u start, u end | axis<<28 | leaf<<30 }   (bih.h:92-98)
-//   object    14 slots: [0..3]  globalInverseTransform columns
-//                       [4..6]  globalInverseNormalTransform (9 f), u mesh_begin, u mesh_count, 0
-//                       [7..10] globalTransform columns
-//                       [11..13] globalNormalTransform (9 f), 0, 0, 0
+//   object    16 slots: [0]     world box min - margin (3 f), u flags (kObj* below)
+//                       [1]     world box max + margin (3 f), 0
+//                       [2..5]  globalInverseTransform columns
+//                       [6..8]  globalInverseNormalTransform (9 f), u mesh_begin, u mesh_count, 0
+//                       [9..12] globalTransform columns
+//                       [13..15] globalNormalTransform (9 f), 0, 0, 0
 //   mesh       3 slots: { f min.xyz, u material } { f max.xyz, u node_begin } { u tri_begin, u depth, 0, 0 }
 //   triangle   3 slots: { a.x a.y a.z e1.x } { e1.y e1.z e2.x e2.y } { e2.z, u prim_id, 0, 0 }
 //                       with a = p0, e1 = p1 - p0, e2 = p2 - p0 (math.h:132-133)
@@ -34,7 +36,10 @@ namespace dev
 	constexpr uint32_t kNodeAxisShift = 28;
 	constexpr uint32_t kNodeEndMask = (1u << 28) - 1;
 
-	constexpr uint32_t kObjectSlots = 14;
+	constexpr uint32_t kObjectSlots = 16;
+	constexpr uint32_t kObjPrefilter = 1u;  // slots 0-1 hold a usable conservative world box
+	constexpr uint32_t kObjInvAffine = 2u;  // globalInverseTransform has bottom row (0,0,0,1): hom.w == 1, the divide is the identity
+	constexpr uint32_t kObjFwdAffine = 4u;  // same for globalTransform
 	constexpr uint32_t kMeshSlots = 3;
 	constexpr uint32_t kTriSlots = 3;
 	constexpr uint32_t kNormalSlots = 3;

@@ -313,6 +313,12 @@ namespace math
 		const vec4 hom = m * vec4(v, 1.0f);
 		return vec3(hom.x, hom.y, hom.z) / hom.w;
 	}
+	// the same with hom.w known to be exactly 1 (bottom row (0,0,0,1)): x / 1.0f == x, the divide drops out
+	ACR_HD vec3 translateAffine(const mat4 &m, const vec3 &v)
+	{
+		const vec4 hom = m * vec4(v, 1.0f);
+		return vec3(hom.x, hom.y, hom.z);
+	}
 	// math.h:180-183
 	ACR_HD vec3 translaten(const mat3 &m, const vec3 &v) { return normalize(m * v); }
 

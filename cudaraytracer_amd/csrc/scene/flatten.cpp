@@ -53,6 +53,8 @@ namespace acr
 			pushMat4(a.objInvTransform, o.globalInverseTransform);
 			pushMat3(a.objNormal, o.globalNormalTransform);
 			pushMat3(a.objInvNormal, o.globalInverseNormalTransform);
+			pushVec3(a.objWorldMin, o.boundingBox.min);
+			pushVec3(a.objWorldMax, o.boundingBox.max);
 			a.objMeshBegin.push_back(uint32_t(a.objMeshIds.size()));
 			a.objMeshCount.push_back(uint32_t(o.meshes.size()));
 			for (size_t k = 0; k < o.meshes.size(); k++)
@@ -108,6 +110,7 @@ namespace acr
 		v.num_objects = uint32_t(objs.size());
 		v.obj_transform = a.objTransform.data(); v.obj_inv_transform = a.objInvTransform.data();
 		v.obj_normal_transform = a.objNormal.data(); v.obj_inv_normal_transform = a.objInvNormal.data();
+		v.obj_world_min = a.objWorldMin.data(); v.obj_world_max = a.objWorldMax.data();
 		v.obj_mesh_begin = a.objMeshBegin.data(); v.obj_mesh_count = a.objMeshCount.data();
 		v.num_obj_mesh_ids = uint32_t(a.objMeshIds.size()); v.obj_mesh_ids = a.objMeshIds.data();
 		v.num_meshes = uint32_t(meshes.size());

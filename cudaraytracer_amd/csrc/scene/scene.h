@@ -81,7 +81,7 @@ namespace acr
 		std::vector<uint32_t> snodeStart, snodeEnd;
 		std::vector<float> snodeLeft, snodeRight;
 		std::vector<uint8_t> snodeFlags;
-		std::vector<float> objTransform, objInvTransform, objNormal, objInvNormal;
+		std::vector<float> objTransform, objInvTransform, objNormal, objInvNormal, objWorldMin, objWorldMax;
 		std::vector<uint32_t> objMeshBegin, objMeshCount, objMeshIds;
 		std::vector<float> meshMin, meshMax;
 		std::vector<uint32_t> meshMaterial, meshDepth, meshNodeBegin, meshTriBegin;

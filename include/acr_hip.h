@@ -75,6 +75,8 @@ typedef struct acr_scene_soa {
 	const float *obj_inv_transform;            /* 16 each: globalInverseTransform        (scene.cu:365) */
 	const float *obj_normal_transform;         /*  9 each: globalNormalTransform         (scene.cu:366) */
 	const float *obj_inv_normal_transform;     /*  9 each: globalInverseNormalTransform  (scene.cu:367) */
+	const float *obj_world_min, *obj_world_max; /* 3 each: Object::boundingBox, world space (scene.cu:392); may be NULL.
+	                                             * Only used to skip objects a ray misses by a wide margin; results do not depend on it. */
 	const uint32_t *obj_mesh_begin;            /* into obj_mesh_ids */
 	const uint32_t *obj_mesh_count;            /* Object::meshes.size() (scene.cu:404) */
 	uint32_t num_obj_mesh_ids;

@@ -757,6 +757,7 @@ static int mesh_intersect(const mesh_t *m, const ray_t *r, hitinfo_t *info, stat
 	fc.vertices = m->vertices;
 	fc.prim_base = m->prim_base;
 	if (bbox_intersect_args(&m->boundingBox, r, info->t, &args, st)
+	    && (st->c.mesh_box_hits++, 1)
 	    && bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st)) {
 		info->materialIndex = m->materialIndex;
 		return 1;
@@ -1323,7 +1324,7 @@ static void counters_add(orc_counters *a, const orc_counters *b)
 	a->rays_primary += b->rays_primary; a->rays_shadow += b->rays_shadow; a->rays_bounce += b->rays_bounce;
 	a->primary_hits += b->primary_hits; a->node_visits += b->node_visits; a->slab_tests += b->slab_tests;
 	a->object_visits += b->object_visits; a->mesh_visits += b->mesh_visits; a->triangle_tests += b->triangle_tests;
-	a->object_hits += b->object_hits;
+	a->object_hits += b->object_hits; a->mesh_box_hits += b->mesh_box_hits;
 }
 
 int orc_render(const orc_scene *s, const orc_camera *cam_in, const orc_frame *f,

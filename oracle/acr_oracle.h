@@ -102,6 +102,7 @@ typedef struct orc_counters {
 	uint64_t mesh_visits;     /* Mesh::intersect calls */
 	uint64_t triangle_tests;  /* Face::intersect calls */
 	uint64_t object_hits;     /* Object::intersect calls whose local ray hit something (scene.cu:426-437 runs) */
+	uint64_t mesh_box_hits;   /* Mesh::intersect calls that passed the mesh box test (geometry.cu:55) */
 } orc_counters;
 
 typedef struct orc_frame {

@@ -52,7 +52,7 @@ def main():
         r = o.render(w, h, seed=seed, frames=0, max_bounces=b, aov=False)
         c = r["counters"]
         rays = c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
-        c["per_ray"] = {k: round(c[k] / rays, 4) for k in ("node_visits", "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits")}
+        c["per_ray"] = {k: round(c[k] / rays, 4) for k in ("node_visits", "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits", "mesh_box_hits")}
         counters[label] = dict(scene=name, width=w, height=h, max_bounces=b, seed=seed, **c)
         print(label, c)
     with open(os.path.join(HERE, "oracle_counters.json"), "w") as f:

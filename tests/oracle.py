@@ -26,7 +26,7 @@ class OrcNode(C.Structure):
 
 class OrcCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_bounce", "primary_hits", "node_visits",
-                                          "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits")]
+                                          "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits", "mesh_box_hits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
