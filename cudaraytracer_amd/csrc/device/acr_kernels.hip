@@ -525,7 +525,7 @@ __device__ __forceinline__ void stageScene(const uint4 *__restrict__ g, uint32_t
 
 // scatterTrace (renderer.cu:326-388) with rayColor<N> (renderer.cu:232-324) unrolled into a loop.
 template <bool SMALL_LDS, bool LARGE_LDS>
-__global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
+__global__ void __launch_bounds__(kBlock, 4) renderKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
 	SceneMem<SMALL_LDS, LARGE_LDS> mem;
@@ -593,8 +593,8 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 		vec3 source(1, 1, 1);
 		vec4 tail(0, 0, 0, 1);
 		uint32_t level = 0;
-		uint32_t primId = 0xFFFFFFFFu;
-		float primT = FLT_MAX;
+		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
+		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
 		for (;;) {
 			if (level == p.max_bounces) // rayColor<0> (renderer.cu:318-324)
 				break;
@@ -608,19 +608,19 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 			if (!sceneIntersect<false>(mem, sc, r, info, 0.0f, undoScene, undoMesh))
 				break; // renderer.cu:315
 			if (level == 0) {
-				primId = info.prim;
-				primT = info.t;
+				if (p.primid) p.primid[outSlot] = info.prim;
+				if (p.hit_t) p.hit_t[outSlot] = info.t;
 				cnt.primaryHits++;
 			}
+			// direct illum (renderer.cu:247-248); the material record is fetched after the shadow rays
+			const vec3 lightSum = lightPoint(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh);
 			const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
 			const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
 			const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
 			const float refractiveIndex = asF(m0.w);
 			const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
 			const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
-
-			// direct illum (renderer.cu:247-248)
-			const vec3 c = ambient + diffuse * lightPoint(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh);
+			const vec3 c = ambient + diffuse * lightSum;
 
 			// indirect illum.  nSource is uninitialised in the reference's
 			// translucent branch (renderer.cu:251,286-311); defined as `source` here.
@@ -696,8 +696,6 @@ __global__ void __launch_bounds__(kBlock) renderKernel(const RenderParams p)
 		} else {
 			*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
 		}
-		if (p.primid) p.primid[outSlot] = primId;
-		if (p.hit_t) p.hit_t[outSlot] = primT;
 	}
 
 	if (tiled && (p.tile_rays || p.tile_cycles)) {

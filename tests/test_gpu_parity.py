@@ -188,10 +188,10 @@ def test_trace_rays_matches_oracle(core, built, name):
     assert h.sum() > 100
 
 
-@pytest.mark.parametrize("ntri,depth,mode", [(400, 6, 2), (3000, 10, 1), (60000, 14, 0)])
+@pytest.mark.parametrize("ntri,depth,mode", [(150, 6, 2), (3000, 10, 1), (60000, 14, 0)])
 def test_soup_deeper_bih_and_lds_modes(core, acr, orc, ntri, depth, mode):
     """procedural soup at larger BIH depths: scene fully in LDS / only the small tables / nothing staged"""
-    b = Built(acr, orc, soup_data(acr, ntri, seed=4, edge=0.08), mesh_depth=depth)
+    b = Built(acr, orc, soup_data(acr, ntri, seed=4, edge=0.08 if ntri > 1000 else 0.3), mesh_depth=depth)
     load(core, b)
     w, h = 192, 108
     img, pid, ht, st = render(core, w, h, seed=11, frames=0, max_bounces=2)
