@@ -68,11 +68,19 @@ def main():
                          f"--nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # ACR_BENCH_REHEARSAL=1 runs the multi-rank path on ONE GPU (every rank on device 0, gloo, tiles staged
+    # through the host): a functional rehearsal for boxes with a single GPU, never a measurement.
+    rehearsal = os.environ.get("ACR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     data = acr.ImportData.load(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".json"))
     view, keep = data.pack()
@@ -130,7 +138,7 @@ def main():
             return a
         dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
-                                   rebalance=True, cost_lag=2)
+                                   rebalance_every=16, stage_through_host=rehearsal)
         ray_sums = []
         for _ in range(args.warmup):
             dr.render_frame()
@@ -138,11 +146,25 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             dr.render_frame()
-            ray_sums.append(dr.last_cost.sum())  # device scalar, no sync
+            ray_sums.append(dr.rays_last_frame())  # device scalar, no sync
         barrier()
         elapsed = time.perf_counter() - t0
-        rays = int(torch.stack(ray_sums).double().sum().item())
+        local = torch.stack(ray_sums).double().sum().reshape(1)
+        if rehearsal:
+            local = local.cpu()
+        dist.all_reduce(local)  # each rank counted the rays of its own tiles
+        rays = int(local.item())
         lds_bytes = lds_mode = None
+        if rank == 0 and os.environ.get("ACR_BENCH_CHECK") == "1":
+            # functional check of the assembled frame against a single full-frame render of the same seed
+            last_seed = seed0 + step_no[0] - 1
+            full = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=device)
+            core.render(WIDTH, HEIGHT, seed=last_seed, frames=0, max_bounces=MAX_BOUNCES, screen_dev=C.c_void_p(full.data_ptr()))
+            torch.cuda.synchronize()
+            same = bool(torch.equal(full.view(torch.int32), dr.frame.view(torch.int32)))
+            print(f"[check] assembled frame equals single-GPU frame: {same}; split {[int(x) for x in dr.plan.begin]}", file=sys.stderr)
+            if not same:
+                raise SystemExit("assembled frame differs from the full-frame render")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

@@ -48,9 +48,13 @@ struct acr_hip_ctx
 
 	// per-launch scratch
 	unsigned long long *counters = nullptr; // device [kCounterSlots][4]
-	uint32_t *tileIds = nullptr;            // device copy of the tile list
-	std::vector<uint32_t> tileIdsHost;      // stays alive while the async copy reads it
-	size_t tileIdsCap = 0;
+	// device copies of the last tile lists (render / scatter); re-uploaded only when the list changes
+	struct TileList
+	{
+		uint32_t *dev = nullptr;
+		size_t cap = 0;
+		std::vector<uint32_t> host;
+	} renderTiles, scatterTiles;
 	hipEvent_t evStart = nullptr, evStop = nullptr;
 	bool timed = false;
 	acr_stats stats{};
@@ -152,6 +156,24 @@ namespace
 		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
 		return p;
 	}
+	// Makes list.dev hold `ids`.  A list equal to the previous one costs a memcmp; a new one waits for the
+	// stream (earlier launches may still read the old copy) and uploads.
+	int syncTileList(acr_hip_ctx *ctx, acr_hip_ctx::TileList &list, const uint32_t *ids, uint32_t n)
+	{
+		if (list.host.size() == n && memcmp(list.host.data(), ids, sizeof(uint32_t) * n) == 0) return ACR_OK;
+		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (list.cap < n) {
+			(void)hipFree(list.dev);
+			list.dev = nullptr;
+			list.cap = 0;
+			list.host.clear();
+			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&list.dev), sizeof(uint32_t) * n));
+			list.cap = n;
+		}
+		list.host.assign(ids, ids + n);
+		ACR_HIP_TRY(ctx, hipMemcpy(list.dev, list.host.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+		return ACR_OK;
+	}
 } // namespace
 
 extern "C" {
@@ -187,7 +209,8 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->hitT);
 	(void)hipFree(ctx->pixelValues);
 	(void)hipFree(ctx->counters);
-	(void)hipFree(ctx->tileIds);
+	(void)hipFree(ctx->renderTiles.dev);
+	(void)hipFree(ctx->scatterTiles.dev);
 	if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
 	if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
 	if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -458,17 +481,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (tiled) {
-		if (ctx->tileIdsCap < f->num_tiles) {
-			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-			(void)hipFree(ctx->tileIds);
-			ctx->tileIds = nullptr;
-			ctx->tileIdsCap = 0;
-			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->tileIds), sizeof(uint32_t) * f->num_tiles));
-			ctx->tileIdsCap = f->num_tiles;
-		}
-		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		ctx->tileIdsHost.assign(f->tile_ids, f->tile_ids + f->num_tiles);
-		ACR_HIP_TRY(ctx, hipMemcpyAsync(ctx->tileIds, ctx->tileIdsHost.data(), sizeof(uint32_t) * f->num_tiles, hipMemcpyHostToDevice, ctx->stream));
+		const int rc = syncTileList(ctx, ctx->renderTiles, f->tile_ids, f->num_tiles);
+		if (rc != ACR_OK) return rc;
 	}
 
 	RenderParams p{};
@@ -489,7 +503,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	p.tile_h = f->tile_h;
 	p.tiles_x = tilesX;
 	p.num_tiles = f->num_tiles;
-	p.tile_ids = ctx->tileIds;
+	p.tile_ids = ctx->renderTiles.dev;
 	p.pixel_values = f->pixel_values_dev;
 	p.screen = ownBuffers ? ctx->screen : static_cast<float4 *>(screen_dev);
 	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
@@ -628,18 +642,9 @@ int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_
 	for (uint32_t i = 0; i < num_tiles; i++)
 		if (tile_ids[i] >= tilesX * tilesY) return fail(ctx, ACR_ERR_INVALID, "tile_ids[%u] out of range", i);
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (ctx->tileIdsCap < num_tiles) {
-		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		(void)hipFree(ctx->tileIds);
-		ctx->tileIds = nullptr;
-		ctx->tileIdsCap = 0;
-		ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->tileIds), sizeof(uint32_t) * num_tiles));
-		ctx->tileIdsCap = num_tiles;
-	}
-	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	ctx->tileIdsHost.assign(tile_ids, tile_ids + num_tiles);
-	ACR_HIP_TRY(ctx, hipMemcpyAsync(ctx->tileIds, ctx->tileIdsHost.data(), sizeof(uint32_t) * num_tiles, hipMemcpyHostToDevice, ctx->stream));
-	ACR_HIP_TRY(ctx, acr_dev_launch_scatter_tiles(tiles_dev, ctx->tileIds, num_tiles, tile_w, tile_h, width, height, frame_dev, ctx->stream));
+	const int rc = syncTileList(ctx, ctx->scatterTiles, tile_ids, num_tiles);
+	if (rc != ACR_OK) return rc;
+	ACR_HIP_TRY(ctx, acr_dev_launch_scatter_tiles(tiles_dev, ctx->scatterTiles.dev, num_tiles, tile_w, tile_h, width, height, frame_dev, ctx->stream));
 	return ACR_OK;
 }
 

@@ -90,28 +90,42 @@ class TiledFrame:
 
 
 class DistributedRenderer:
-    """Renders frames across the ranks of the default process group and assembles them on rank 0."""
+    """Renders frames across the ranks of the default process group and assembles them on rank 0.
 
-    def __init__(self, width, height, render_tiles, device, tile_w=64, tile_h=16, scatter=None, rebalance=True, cost_lag=0):
+    All tile buffers are kept in Z-curve order.  The runs of the ranks, concatenated in rank order, are the
+    whole curve whatever the split, so rank 0 owns one buffer [num_tiles][tile pixels] float4: it renders its
+    own run straight into the front slice, receives rank r's run straight into slice [begin[r], begin[r+1])
+    (no staging copy), and one scatter with the fixed Z-order list writes the frame.  Per-tile costs live in
+    one [num_tiles] vector in the same order."""
+
+    def __init__(self, width, height, render_tiles, device, tile_w=64, tile_h=16, scatter=None, rebalance_every=1,
+                 stage_through_host=False):
         """scatter(tiles, tile_ids, frame): writes compact tiles into the full frame tensor
         [height, width, 4] on rank 0; None selects a torch implementation.
-        cost_lag: a frame's measured costs steer the assignment `cost_lag` frames later (every rank
-        applies them at the same frame, so the assignment stays identical everywhere); a lag of 2 lets
-        the device-to-host copy of the cost vector finish behind the next frame instead of stalling it."""
+        rebalance_every: the assignment is rebuilt from the measured costs every this many frames (0 = never);
+        the reference re-sorts its pixel table every 60 still frames (renderer.cu:392,457).
+        stage_through_host: move tiles and costs through CPU tensors for the exchange (for a process group
+        whose backend cannot carry device tensors, e.g. gloo when rehearsing the multi-rank path on one GPU)."""
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.device = device
         self.render_tiles = render_tiles
         self.scatter = scatter or self._scatter_torch
-        self.rebalance = rebalance
-        self.cost_lag = cost_lag
-        self._pending = []  # (host tensor, event or None) per frame, oldest first
+        self.rebalance_every = rebalance_every
+        self.stage_through_host = stage_through_host
         self.plan = TiledFrame(width, height, self.world, tile_w, tile_h)
-        self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if self.rank == 0 else None
         self.tile_px = tile_w * tile_h
+        self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if self.rank == 0 else None
+        n = self.plan.num_tiles
+        # rank 0 holds every tile; the others only ever hold their own run (sized for the largest possible run)
+        self.tiles = torch.zeros((n, self.tile_px, 4), dtype=torch.float32, device=device)
+        self.cost = torch.zeros(n, dtype=torch.int32, device=device)  # Z-order; only this rank's run is ever non-zero
+        self.frames_since_rebalance = 0
+        self.last_cost = self.cost
+        self._rays_last = torch.zeros((), dtype=torch.int64, device=device)
 
     def camera_moved(self):
-        self._pending.clear()
+        self.frames_since_rebalance = 0
         self.plan.reset()
 
     def _scatter_torch(self, tiles, tile_ids, frame):
@@ -125,69 +139,66 @@ class DistributedRenderer:
     def render_frame(self):
         """One frame.  Returns the assembled frame tensor on rank 0, None elsewhere."""
         p = self.plan
-        mine = np.ascontiguousarray(p.tiles_of(self.rank), dtype=np.uint32)
-        out = torch.empty((len(mine), self.tile_px, 4), dtype=torch.float32, device=self.device)
-        cost = torch.zeros(len(mine), dtype=torch.float32, device=self.device)
-        if len(mine):
-            self.render_tiles(mine, out, cost)
+        b0, b1 = int(p.begin[self.rank]), int(p.begin[self.rank + 1])
+        # rank 0 keeps its run at its Z position; other ranks use the front of their buffer
+        at = b0 if self.rank == 0 else 0
+        out = self.tiles[at:at + (b1 - b0)]
+        cost = self.cost[b0:b1]
+        if b1 > b0:
+            self.render_tiles(p.order[b0:b1], out, cost)
 
         if self.world > 1:
-            # gather with unequal counts: rank 0 receives every other rank's run of tiles
             ops, staged = [], {}
             if self.rank == 0:
                 for r in range(1, self.world):
-                    n = int(p.begin[r + 1]) - int(p.begin[r])
-                    if n:
-                        staged[r] = torch.empty((n, self.tile_px, 4), dtype=torch.float32, device=self.device)
-                        ops.append(dist.P2POp(dist.irecv, staged[r], r))
-            elif len(mine):
-                ops.append(dist.P2POp(dist.isend, out, 0))
+                    rb0, rb1 = int(p.begin[r]), int(p.begin[r + 1])
+                    if rb1 > rb0:
+                        dst = self.tiles[rb0:rb1]
+                        if self.stage_through_host:
+                            staged[r] = torch.empty(dst.shape, dtype=dst.dtype)
+                            dst = staged[r]
+                        ops.append(dist.P2POp(dist.irecv, dst, r))
+            elif b1 > b0:
+                ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
             works = dist.batch_isend_irecv(ops) if ops else []
-            # cost feedback: every rank contributes its tiles' costs, all ranks get the full vector
-            full_cost = torch.zeros(p.num_tiles, dtype=torch.float32, device=self.device)
-            if len(mine):
-                full_cost[torch.as_tensor(mine.astype(np.int64), device=self.device)] = cost
-            dist.all_reduce(full_cost)
             for w in works:
                 w.wait()
-        else:
-            staged = {}
-            full_cost = torch.zeros(p.num_tiles, dtype=torch.float32, device=self.device)
-            if len(mine):
-                full_cost[torch.as_tensor(mine.astype(np.int64), device=self.device)] = cost
+            for r, buf in staged.items():
+                self.tiles[int(p.begin[r]):int(p.begin[r + 1])].copy_(buf)
 
         if self.rank == 0:
-            if len(mine):
-                self.scatter(out, mine, self.frame)
-            for r, buf in staged.items():
-                self.scatter(buf, np.ascontiguousarray(p.tiles_of(r), dtype=np.uint32), self.frame)
-        self.last_cost = full_cost  # device tensor: per-tile cost of this frame (ray counts with the HIP core)
-        if self.rebalance:
-            if full_cost.is_cuda:
-                host = torch.empty(full_cost.shape, dtype=full_cost.dtype, pin_memory=True)
-                host.copy_(full_cost, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-            else:
-                host, ev = full_cost.clone(), None
-            self._pending.append((host, ev))
-            if len(self._pending) > self.cost_lag:
-                host, ev = self._pending.pop(0)
-                if ev is not None:
-                    ev.synchronize()
-                p.update(host.numpy())
+            self.scatter(self.tiles, p.order, self.frame)
+
+        self.last_cost = self.cost
+        self._rays_last = cost.sum() if b1 > b0 else torch.zeros((), dtype=torch.int64, device=self.device)
+        self.frames_since_rebalance += 1
+        if self.rebalance_every and self.frames_since_rebalance >= self.rebalance_every:
+            self.frames_since_rebalance = 0
+            full = self.cost.to(torch.float32)
+            if self.world > 1:
+                if self.stage_through_host:
+                    full = full.cpu()
+                dist.all_reduce(full)  # every rank contributes its run; all ranks get the whole vector
+            cost_z = full.cpu().numpy()
+            by_tile = np.zeros(p.num_tiles, dtype=np.float32)
+            by_tile[p.order] = cost_z
+            if b1 > b0:
+                self.cost[b0:b1].zero_()  # the next run may start elsewhere: leave no stale costs behind
+            p.update(by_tile)
         return self.frame
+
+    def rays_last_frame(self):
+        """Device scalar: rays this rank traced in the last frame (sum of its per-tile costs when the cost is a ray count)."""
+        return self._rays_last
 
 
 def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args):
-    """render_tiles callable over a HipCore: renders straight into the torch
-    tensors' device memory through the C ABI (ray counts as the tile cost)."""
+    """render_tiles callable over a HipCore: renders straight into the torch tensors' device memory through
+    the C ABI; the per-tile cost is the number of rays traced."""
     def fn(tile_ids, out, cost):
-        rays = torch.zeros(len(tile_ids), dtype=torch.int32, device=out.device)
         args = frame_args() if callable(frame_args) else dict(frame_args)
         core.render(width, height, tile_ids=tile_ids, tile_w=tile_w, tile_h=tile_h, screen_dev=C.c_void_p(out.data_ptr()),
-                    tile_rays_dev=C.c_void_p(rays.data_ptr()), **args)
-        cost.copy_(rays.to(torch.float32))
+                    tile_rays_dev=C.c_void_p(cost.data_ptr()), **args)
     return fn
 
 

@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_path):
             buf[k, :h, :w] = img[y0:y0 + h, x0:x0 + w]
             c[k] = 1.0 + float((r["prim"][y0:y0 + h, x0:x0 + w] != 0xFFFFFFFF).sum())
         out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
-        cost.copy_(torch.from_numpy(c))
+        cost.copy_(torch.from_numpy(c.astype(np.int32)))
         rendered.append(len(tile_ids))
 
     dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
@@ -107,7 +107,7 @@ def test_single_rank_path_without_process_group():
             w, h = min(TW, W - x0), min(TH, H - y0)
             buf[k, :h, :w] = ref[y0:y0 + h, x0:x0 + w]
         out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
-        cost.fill_(1.0)
+        cost.fill_(1)
 
     dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
     frame = dr.render_frame()
