@@ -94,7 +94,8 @@ class Frame(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("kernel_ms", C.c_float), ("lds_bytes", C.c_uint32),
-                ("scene_in_lds", C.c_uint32), ("grid_blocks", C.c_uint32)]
+                ("scene_in_lds", C.c_uint32), ("grid_blocks", C.c_uint32), ("interval_traversal", C.c_uint32),
+                ("six_plane_pixels", C.c_uint32)]
 
 
 # every symbol include/acr_hip.h declares: name -> (restype, argtypes)
@@ -105,6 +106,7 @@ HIP_SYMBOLS = {
     "acr_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "acr_hip_use_own_stream": (C.c_int, [C.c_void_p]),
     "acr_hip_sync": (C.c_int, [C.c_void_p]),
+    "acr_hip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "acr_hip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneSoA)]),
     "acr_hip_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_hip_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),

@@ -150,6 +150,11 @@ class HipCore:
     def use_own_stream(self):
         self._check(self._lib.acr_hip_use_own_stream(self._h), "acr_hip_use_own_stream")
 
+    def set_traversal(self, six_plane_only):
+        """False (default): interval form of the slab test wherever it is provably identical; True: the
+        six-plane form as written in the reference for every ray."""
+        self._check(self._lib.acr_hip_set_traversal(self._h, 1 if six_plane_only else 0), "acr_hip_set_traversal")
+
     def resize(self, w, h):
         self._check(self._lib.acr_hip_resize(self._h, w, h), "acr_hip_resize")
         self._w, self._hh = w, h

@@ -55,6 +55,14 @@ struct acr_hip_ctx
 		size_t cap = 0;
 		std::vector<uint32_t> host;
 	} renderTiles, scatterTiles;
+	// interval traversal (see acr_kernels.hip): usable for this scene, forced off by the caller, and the
+	// buffers through which its launches hand pixels to the six-plane list pass
+	bool intervalOk = false;
+	int traversalMode = ACR_TRAVERSAL_AUTO;
+	uint32_t *redoCount = nullptr; // device [2], used alternately by successive frames
+	uint32_t *redoList = nullptr;
+	size_t redoCap = 0;
+	uint32_t redoParity = 0;
 	hipEvent_t evStart = nullptr, evStop = nullptr;
 	bool timed = false;
 	acr_stats stats{};
@@ -95,6 +103,34 @@ namespace
 	// Walks the nodes reachable from the root and checks what the kernels rely on:
 	// an internal node has both children inside the heap, a leaf's item range is
 	// inside [0, itemCount].
+	// True when every split plane a traversal can reach lies inside the box of its node (the root box
+	// clipped by the ancestors' planes) and the root box has min <= max: the precondition of the interval
+	// form of the slab test.  sift() always builds such trees for non-empty item sets.
+	bool planesInsideBoxes(const float *rootMin, const float *rootMax, const float *left, const float *right, const uint8_t *flags)
+	{
+		struct Item { uint32_t i; float mn[3], mx[3]; };
+		for (int k = 0; k < 3; k++)
+			if (!(rootMin[k] <= rootMax[k]) || !std::isfinite(rootMin[k]) || !std::isfinite(rootMax[k])) return false;
+		std::vector<Item> todo(1);
+		todo[0].i = 0;
+		memcpy(todo[0].mn, rootMin, 12);
+		memcpy(todo[0].mx, rootMax, 12);
+		while (!todo.empty()) {
+			const Item it = todo.back();
+			todo.pop_back();
+			if (flags[it.i] & ACR_NODE_LEAF) continue;
+			const uint32_t a = flags[it.i] & ACR_NODE_AXIS_MASK;
+			const float l = left[it.i], r = right[it.i];
+			if (!(it.mn[a] <= l && l <= it.mx[a] && it.mn[a] <= r && r <= it.mx[a])) return false;
+			Item L = it, R = it;
+			L.i = 2 * it.i + 1; L.mx[a] = l;
+			R.i = 2 * it.i + 2; R.mn[a] = r;
+			todo.push_back(R);
+			todo.push_back(L);
+		}
+		return true;
+	}
+
 	bool checkBih(uint32_t depth, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t itemCount, std::string &why,
 	              uint32_t *levelsUsed)
 	{
@@ -140,7 +176,9 @@ namespace
 	// Decides how much of the scene a workgroup stages into LDS.
 	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels)
 	{
-		const size_t stackFloats = size_t(h.scene_depth + h.max_mesh_depth + 3 * colorLevels) * kBlock;
+		// two floats per tree level and lane (the interval traversal's waiting-child column; the six-plane
+		// traversal uses one of them as its undo column), three per bounce level for the direct terms
+		const size_t stackFloats = size_t(2 * (h.scene_depth + h.max_mesh_depth) + 3 * colorLevels) * kBlock;
 		const size_t stackBytes = stackFloats * 4;
 		LaunchPlan p;
 		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {
@@ -189,6 +227,8 @@ int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
 	ctx->device = device_ordinal;
 	if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->counters), kCounterSlots * 4 * sizeof(unsigned long long)) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&ctx->redoCount), 2 * sizeof(uint32_t)) != hipSuccess ||
+	    hipMemset(ctx->redoCount, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
 	    hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess) {
 		acr_hip_destroy(ctx);
 		return ACR_ERR_HIP;
@@ -209,6 +249,8 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->hitT);
 	(void)hipFree(ctx->pixelValues);
 	(void)hipFree(ctx->counters);
+	(void)hipFree(ctx->redoCount);
+	(void)hipFree(ctx->redoList);
 	(void)hipFree(ctx->renderTiles.dev);
 	(void)hipFree(ctx->scatterTiles.dev);
 	if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -230,6 +272,13 @@ int acr_hip_use_own_stream(acr_hip_ctx *ctx)
 {
 	if (!ctx) return ACR_ERR_INVALID;
 	ctx->stream = ctx->ownStream;
+	return ACR_OK;
+}
+
+int acr_hip_set_traversal(acr_hip_ctx *ctx, int mode)
+{
+	if (!ctx || (mode != ACR_TRAVERSAL_AUTO && mode != ACR_TRAVERSAL_SIX_PLANE)) return fail(ctx, ACR_ERR_INVALID, "unknown traversal mode");
+	ctx->traversalMode = mode;
 	return ACR_OK;
 }
 
@@ -283,6 +332,12 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	}
 	for (uint32_t i = 0; i < s->num_lights; i++)
 		if (s->light_type[i] < 0 || s->light_type[i] > 2) return fail(ctx, ACR_ERR_INVALID, "light %u: unknown type", i);
+	// does the scene qualify for the interval traversal?
+	bool intervalOk = planesInsideBoxes(s->scene_min, s->scene_max, s->snode_left, s->snode_right, s->snode_flags);
+	for (uint32_t m = 0; m < s->num_meshes && intervalOk; m++) {
+		const uint32_t nb = s->mesh_node_begin[m];
+		intervalOk = planesInsideBoxes(s->mesh_min + 3 * size_t(m), s->mesh_max + 3 * size_t(m), s->mnode_left + nb, s->mnode_right + nb, s->mnode_flags + nb);
+	}
 
 	// ---- pack ----
 	SceneHeader h{};
@@ -412,6 +467,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->blob), ctx->blobBytes));
 	ACR_HIP_TRY(ctx, hipMemcpy(ctx->blob, blob.data(), ctx->blobBytes, hipMemcpyHostToDevice));
 	ctx->header = h;
+	ctx->intervalOk = intervalOk;
 	ctx->haveScene = true;
 	return ACR_OK;
 }
@@ -516,18 +572,35 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 
 	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0);
 	p.lds_stack_slot = plan.stackSlot;
+	const bool fast = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO;
+	if (fast) {
+		const size_t slots = size_t(grid) * kBlock;
+		if (ctx->redoCap < slots) {
+			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			(void)hipFree(ctx->redoList);
+			ctx->redoList = nullptr;
+			ctx->redoCap = 0;
+			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->redoList), slots * sizeof(uint32_t)));
+			ctx->redoCap = slots;
+		}
+		p.redo_list = ctx->redoList;
+		p.redo_count = ctx->redoCount + ctx->redoParity;
+		p.redo_count_next = ctx->redoCount + (ctx->redoParity ^ 1u);
+		ctx->redoParity ^= 1u;
+	}
 
 	ctx->timed = f->collect_stats != 0;
 	if (ctx->timed) {
 		ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
 		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
 	}
-	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, grid, plan.ldsBytes, ctx->stream));
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, fast ? 1 : 0, grid, plan.ldsBytes, ctx->stream));
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
 	ctx->stats = acr_stats{};
 	ctx->stats.lds_bytes = uint32_t(plan.ldsBytes);
 	ctx->stats.scene_in_lds = uint32_t(plan.ldsMode);
 	ctx->stats.grid_blocks = grid;
+	ctx->stats.interval_traversal = fast ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }
@@ -565,7 +638,7 @@ int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const
 		p.hit = dHit; p.t = dT; p.prim = dPrim; p.position = dPos; p.normal = dNrm;
 		const LaunchPlan plan = planLds(ctx->header, 0);
 		p.lds_stack_slot = plan.stackSlot;
-		e = acr_dev_launch_trace(&p, plan.ldsMode, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
+		e = acr_dev_launch_trace(&p, plan.ldsMode, (ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO) ? 1 : 0, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
 	}
 	if (e == hipSuccess && hit) e = hipMemcpyAsync(hit, dHit, n, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess && t) e = hipMemcpyAsync(t, dT, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -625,6 +698,12 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 		float ms = 0;
 		ACR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
 		ctx->stats.kernel_ms = ms;
+		if (ctx->stats.interval_traversal) {
+			// the counter of the last frame is the one the next frame will NOT use; it is zeroed one frame later
+			uint32_t n = 0;
+			ACR_HIP_TRY(ctx, hipMemcpy(&n, ctx->redoCount + (ctx->redoParity ^ 1u), sizeof(n), hipMemcpyDeviceToHost));
+			ctx->stats.six_plane_pixels = n;
+		}
 	}
 	*stats = ctx->stats;
 	return ACR_OK;

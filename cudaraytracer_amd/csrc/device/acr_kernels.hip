@@ -44,6 +44,10 @@ namespace dev
 {
 
 constexpr int kBlock = 256;
+// resident waves per SIMD the render kernel is compiled for (sets its VGPR budget: 512 / waves)
+#ifndef ACR_RENDER_WAVES
+#define ACR_RENDER_WAVES 4
+#endif
 
 extern __shared__ uint4 g_lds[];
 
@@ -207,6 +211,106 @@ __device__ __forceinline__ void bihTraverse(LoadNode loadNode, uint32_t maxDepth
 	}
 }
 
+
+// ---- interval form of the same traversal -----------------------------------
+//
+// When every component of the ray origin and of 1/d is finite and every box
+// handed to the slab test has min <= max on each axis, no plane distance
+// (bound - o) * invD can be NaN and near[i] <= far[i] holds on each axis
+// (subtraction and multiplication by a non-negative value round
+// monotonically).  geometry.h:50-75 then rejects exactly when some near[i]
+// exceeds some far[j], i.e. it accepts iff
+//     max(near) <= min(far)  &&  max(near) < info.t  &&  min(far) > eps.
+// A BIH child box differs from its parent's in ONE plane, and that plane lies
+// inside the parent's box (the host checks this for every reachable node at
+// upload), so the child's max(near) / min(far) are max(parent's, plane) /
+// min(parent's, plane): a lane carries two floats per box instead of six, and
+// the right child that waits while the left subtree is walked is remembered
+// as its two floats in an LDS column indexed by tree level.  Decisions are
+// identical to the six-plane form, so visit order and results are too.
+// Rays that do not qualify (a zero or denormal direction component, i.e. an
+// infinite 1/d) make the pixel leave this kernel; the six-plane kernel
+// renders it afterwards (renderListKernel).
+
+struct Interval
+{
+	float tmin, tmax;
+};
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+__device__ __forceinline__ bool rayIsFinite(const SlabArgs &a)
+{
+	const float inf = __builtin_inff();
+	return fabsf(a.invD.x) < inf && fabsf(a.invD.y) < inf && fabsf(a.invD.z) < inf && fabsf(a.o.x) < inf && fabsf(a.o.y) < inf &&
+	       fabsf(a.o.z) < inf;
+}
+// [max(near), min(far)] of a box with min <= max, for a finite ray
+__device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &mn, const vec3 &mx)
+{
+	const vec3 tmn = (mn - a.o) * a.invD;
+	const vec3 tmx = (mx - a.o) * a.invD;
+	Interval r;
+	r.tmin = fmax3(a.sx ? tmx.x : tmn.x, a.sy ? tmx.y : tmn.y, a.sz ? tmx.z : tmn.z);
+	r.tmax = fmin3(a.sx ? tmn.x : tmx.x, a.sy ? tmn.y : tmx.y, a.sz ? tmn.z : tmx.z);
+	return r;
+}
+__device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) { return tmin <= tmax && tmin < tcur && tmax > epsilon(); }
+
+// bih.h:209-299 on intervals.  `stack` is this lane's column: stack[level * kBlock].
+template <class LoadNode, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, float2 *stack, Leaf leaf, TCur tcur)
+{
+	uint32_t idx = 0, level = 0, pending = 0;
+	float tminB = box.tmin, tmaxB = box.tmax;
+	for (;;) {
+		const uint4 n = loadNode(idx);
+		if ((n.w & kNodeLeafBit) == 0) {
+			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
+			const bool sg = sa.sign(axis);
+			const float tl = sa.plane(axis, asF(n.x)); // lBB.max[axis] = left  (bih.h:244)
+			const float tr = sa.plane(axis, asF(n.y)); // rBB.min[axis] = right (bih.h:245)
+			// The child on the ray's near side keeps the parent's tmin and is cut at its far plane;
+			// the other keeps the parent's tmax and is cut at its near plane.  Left is the near-side
+			// child for a positive direction.
+			const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
+			const float nearSideMax = tCutFar < tmaxB ? tCutFar : tmaxB;
+			const float farSideMin = tCutNear > tminB ? tCutNear : tminB;
+			const float tc = tcur();
+			const bool hitNearSide = intervalHit(tminB, nearSideMax, tc);
+			const bool hitFarSide = intervalHit(farSideMin, tmaxB, tc);
+			const bool hitL = sg ? hitFarSide : hitNearSide;
+			const bool hitR = sg ? hitNearSide : hitFarSide;
+			if (hitL || hitR) {
+				// left first; a right child that also hit waits (bih.h:253-264)
+				const bool takeFarSide = hitL ? sg : !sg;
+				if (hitL && hitR) {
+					pending |= 1u << level;
+					stack[level * kBlock] = takeFarSide ? make_float2(tminB, nearSideMax) : make_float2(farSideMin, tmaxB);
+				}
+				if (takeFarSide) tminB = farSideMin;
+				else tmaxB = nearSideMax;
+				idx = 2 * idx + (hitL ? 1 : 2);
+				level++;
+				continue;
+			}
+		} else {
+			if (leaf(n.z, n.w & kNodeEndMask))
+				return;
+		}
+		// pop: the deepest level whose right child is still waiting
+		if (pending == 0)
+			return;
+		const uint32_t l = 31u - uint32_t(__clz(int(pending)));
+		pending &= ~(1u << l);
+		const float2 b = stack[l * kBlock];
+		tminB = b.x;
+		tmaxB = b.y;
+		idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2; // right child of this path's node on level l
+		level = l + 1;
+	}
+}
+
 // HitInfo (geometry.h:22-27) for the world-space query, plus the primitive id
 struct WorldHit
 {
@@ -248,48 +352,67 @@ __device__ __forceinline__ mat3 loadMat3(const Mem &mem, uint32_t slot, uint32_t
 	return m;
 }
 
-// Mesh::intersect (geometry.cu:52-61) for a local-space ray
+// Face::intersect (geometry.h:123-146) for the items [start, end) of a leaf
 template <class Mem>
+__device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
+                                              struct LocalHit &tmp, bool &intersected);
+
+// Mesh::intersect (geometry.cu:52-61) for a local-space ray
+template <bool FAST, class Mem>
 __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, uint32_t meshId, const Ray &lr,
-                                              const SlabArgs &sa, LocalHit &tmp, float *undo)
+                                              const SlabArgs &sa, LocalHit &tmp, float *stackMesh)
 {
 	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
 	const uint4 q0 = mem.small(ms), q1 = mem.small(ms + 1), q2 = mem.small(ms + 2);
-	SlabBox root;
-	root.init(sa, vec3(asF(q0.x), asF(q0.y), asF(q0.z)), vec3(asF(q1.x), asF(q1.y), asF(q1.z)));
-	// boundingBox.intersect(r, info): the BIH root box is this same box (geometry.cu:47)
-	if (!slabTest(root.nearT, root.farT, tmp.t))
-		return false;
+	const vec3 bmin(asF(q0.x), asF(q0.y), asF(q0.z)), bmax(asF(q1.x), asF(q1.y), asF(q1.z));
 	const uint32_t nodeBase = sc.off_mnodes + q1.w;
 	const uint32_t triBase = sc.off_tris + q2.x * kTriSlots;
 	bool intersected = false;
-	bihTraverse(
-		[&](uint32_t i) { return mem.large(nodeBase + i); }, q2.y, sa, root, undo,
-		[&](uint32_t start, uint32_t end) {
-			for (uint32_t i = start; i < end; i++) {
-				// Face::intersect (geometry.h:123-146)
-				const uint32_t ts = triBase + i * kTriSlots;
-				const uint4 t0 = mem.large(ts), t1 = mem.large(ts + 1), t2 = mem.large(ts + 2);
-				const vec3 a(asF(t0.x), asF(t0.y), asF(t0.z));
-				const vec3 e1(asF(t0.w), asF(t1.x), asF(t1.y));
-				const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
-				vec3 b;
-				float t;
-				if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t) && t < tmp.t) {
-					tmp.t = t;
-					tmp.bary = b;
-					tmp.tri = i + q2.x;
-					intersected = true;
-				}
-			}
+	auto leaf = [&](uint32_t start, uint32_t end) {
+		leafTriangles(mem, triBase, q2.x, start, end, lr, tmp, intersected);
+		return false;
+	};
+	auto loadNode = [&](uint32_t i) { return mem.large(nodeBase + i); };
+	auto tcur = [&]() { return tmp.t; };
+	// boundingBox.intersect(r, info): the BIH root box is this same box (geometry.cu:47)
+	if constexpr (FAST) {
+		const Interval root = boxInterval(sa, bmin, bmax);
+		if (!intervalHit(root.tmin, root.tmax, tmp.t))
 			return false;
-		},
-		[&]() { return tmp.t; });
+		bihTraverseFast(loadNode, sa, root, reinterpret_cast<float2 *>(stackMesh), leaf, tcur);
+	} else {
+		SlabBox root;
+		root.init(sa, bmin, bmax);
+		if (!slabTest(root.nearT, root.farT, tmp.t))
+			return false;
+		bihTraverse(loadNode, q2.y, sa, root, stackMesh, leaf, tcur);
+	}
 	if (intersected) {
 		tmp.material = q0.w;
 		return true;
 	}
 	return false;
+}
+
+template <class Mem>
+__device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
+                                              LocalHit &tmp, bool &intersected)
+{
+	for (uint32_t i = start; i < end; i++) {
+		const uint32_t ts = triBase + i * kTriSlots;
+		const uint4 t0 = mem.large(ts), t1 = mem.large(ts + 1), t2 = mem.large(ts + 2);
+		const vec3 a(asF(t0.x), asF(t0.y), asF(t0.z));
+		const vec3 e1(asF(t0.w), asF(t1.x), asF(t1.y));
+		const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
+		vec3 b;
+		float t;
+		if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t) && t < tmp.t) {
+			tmp.t = t;
+			tmp.bary = b;
+			tmp.tri = i + triFirst;
+			intersected = true;
+		}
+	}
 }
 
 // Object::intersect (scene.cu:407-440).  FULL = false skips what a shadow ray
@@ -305,18 +428,26 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 // purpose (a box beyond the current hit must still report `intersected`).
 // The host sets the flag only for rotation * uniform scale transforms, where
 // the reference's local ray is the true image of the world ray.
-template <bool FULL, class Mem>
+// FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
+template <bool FULL, bool FAST, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, float *undoMesh)
+                                                WorldHit &info, float *undoMesh, bool &bail)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
 	const uint32_t flags = b0.w;
 	if (flags & kObjPrefilter) {
-		SlabBox wb;
-		wb.init(saWorld, vec3(asF(b0.x), asF(b0.y), asF(b0.z)), vec3(asF(b1.x), asF(b1.y), asF(b1.z)));
-		if (!slabTest(wb.nearT, wb.farT, FLT_MAX))
-			return false;
+		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
+		if constexpr (FAST) {
+			const Interval wb = boxInterval(saWorld, wmin, wmax);
+			if (!intervalHit(wb.tmin, wb.tmax, FLT_MAX))
+				return false;
+		} else {
+			SlabBox wb;
+			wb.init(saWorld, wmin, wmax);
+			if (!slabTest(wb.nearT, wb.farT, FLT_MAX))
+				return false;
+		}
 	}
 	Ray lr;
 	uint32_t meshBegin, meshCount;
@@ -329,6 +460,12 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	}
 	SlabArgs sa;
 	sa.init(lr);
+	if constexpr (FAST) {
+		if (!rayIsFinite(sa)) {
+			bail = true;
+			return false;
+		}
+	}
 
 	bool intersected = false;
 	LocalHit tmp;
@@ -341,7 +478,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		const uint4 ids = mem.small(idSlot);
 		const uint32_t sel = (meshBegin + k) & 3u;
 		const uint32_t meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
-		intersected |= meshIntersect(mem, sc, meshId, lr, sa, tmp, undoMesh);
+		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, undoMesh);
 	}
 
 	if (intersected) {
@@ -380,31 +517,45 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 // objects can be skipped without changing it.  (The boolean `intersected` the
 // reference also tests is implied: info.t can only drop below t through a
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
-template <bool SHADOW, class Mem>
+template <bool SHADOW, bool FAST, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               float *undoScene, float *undoMesh)
+                                               float *undoScene, float *undoMesh, bool &bail)
 {
 	SlabArgs sa;
 	sa.init(r);
-	SlabBox root;
-	root.init(sa, vec3(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), vec3(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]));
+	if constexpr (FAST) {
+		if (!rayIsFinite(sa)) {
+			bail = true;
+			return false;
+		}
+	}
+	const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
 	bool intersected = false;
 	bool occluded = false;
-	bihTraverse(
-		[&](uint32_t i) { return mem.small(sc.off_snodes + i); }, sc.scene_depth, sa, root, undoScene,
-		[&](uint32_t start, uint32_t end) {
-			for (uint32_t i = start; i < end; i++) {
-				intersected |= objectIntersect<!SHADOW>(mem, sc, i, r, sa, info, undoMesh);
-				if constexpr (SHADOW) {
-					if (info.t + epsilon() < lightT) {
-						occluded = true;
-						return true;
-					}
+	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
+	auto leaf = [&](uint32_t start, uint32_t end) {
+		for (uint32_t i = start; i < end; i++) {
+			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, undoMesh, bail);
+			if constexpr (FAST) {
+				if (bail) return true;
+			}
+			if constexpr (SHADOW) {
+				if (info.t + epsilon() < lightT) {
+					occluded = true;
+					return true;
 				}
 			}
-			return false;
-		},
-		[&]() { return info.t; });
+		}
+		return false;
+	};
+	auto tcur = [&]() { return info.t; };
+	if constexpr (FAST) {
+		bihTraverseFast(loadNode, sa, boxInterval(sa, smin, smax), reinterpret_cast<float2 *>(undoScene), leaf, tcur);
+	} else {
+		SlabBox root;
+		root.init(sa, smin, smax);
+		bihTraverse(loadNode, sc.scene_depth, sa, root, undoScene, leaf, tcur);
+	}
 	return SHADOW ? occluded : intersected;
 }
 
@@ -438,9 +589,9 @@ struct Counters
 };
 
 // Scene::lightPoint (scene.cu:273-292) with pointLightAccum (209-231) and spotLightAccum (234-271)
-template <class Mem>
+template <bool FAST, class Mem>
 __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc, const vec3 &pos, const vec3 &norm, RandState &state,
-                                           Counters &cnt, float *undoScene, float *undoMesh)
+                                           Counters &cnt, float *undoScene, float *undoMesh, bool &bail)
 {
 	vec3 light(0, 0, 0);
 	for (uint32_t i = 0; i < sc.num_lights; i++) {
@@ -487,8 +638,11 @@ __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc
 			WorldHit sh;
 			sh.t = t;
 			cnt.shadow++;
-			if (sceneIntersect<true>(mem, sc, sr, sh, t, undoScene, undoMesh))
+			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, undoScene, undoMesh, bail))
 				c = vec3(0, 0, 0);
+			if constexpr (FAST) {
+				if (bail) return light;
+			}
 		}
 		light += c;
 	}
@@ -523,194 +677,219 @@ __device__ __forceinline__ void stageScene(const uint4 *__restrict__ g, uint32_t
 	__syncthreads();
 }
 
-// scatterTrace (renderer.cu:326-388) with rayColor<N> (renderer.cu:232-324) unrolled into a loop.
-template <bool SMALL_LDS, bool LARGE_LDS>
-__global__ void __launch_bounds__(kBlock, 4) renderKernel(const RenderParams p)
+// What one pixel slot reports back to the kernel around it.
+struct SlotResult
+{
+	bool active;        // the slot maps to a pixel inside the frame (renderer.cu:335-338)
+	bool bail;          // FAST only: a ray of this pixel needs the six-plane traversal; nothing was written
+	uint32_t tileNo;    // position in the tile list (tile mode)
+	Counters cnt;
+};
+
+// scatterTrace (renderer.cu:326-388) for one pixel slot, with rayColor<N> (renderer.cu:232-324) unrolled into a loop.
+// (vblock, vtid) name the slot: workgroup vblock of the frame's launch grid, work-item vtid in it.  The LDS
+// columns belong to the executing work-item (threadIdx.x), which need not be vtid.
+template <bool FAST, class Mem>
+__device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
 	const SceneHeader &sc = p.scene;
-	SceneMem<SMALL_LDS, LARGE_LDS> mem;
-	mem.g = p.blob;
-	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
-	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
-
 	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
-	float *undoScene = ldsF + threadIdx.x;
-	float *undoMesh = undoScene + sc.scene_depth * kBlock;
-	float *cstack = undoMesh + sc.max_mesh_depth * kBlock;
+	float *undoScene = ldsF + (FAST ? 2 : 1) * threadIdx.x;
+	float *undoMesh = undoScene + (FAST ? 2 : 1) * sc.scene_depth * kBlock;
+	float *cstack = ldsF + 2 * (sc.scene_depth + sc.max_mesh_depth) * kBlock + threadIdx.x;
 
 	// which pixel slot: 16x16 pixels per workgroup, 8x8 per wave
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t lane = vtid & 63u, wave = vtid >> 6;
 	const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3), ly = (lane >> 3) + ((wave >> 1) << 3);
 	uint32_t oldx, oldy;
 	size_t outSlot;
-	uint32_t tileNoOfBlock = 0;
+	SlotResult res;
+	res.tileNo = 0;
+	res.bail = false;
+	res.cnt = {0, 0, 0};
 	const bool tiled = p.num_tiles != 0;
-	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
 	if (tiled) {
 		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
-		const uint32_t tileNo = blockIdx.x / bpt, sub = blockIdx.x % bpt;
+		const uint32_t tileNo = vblock / bpt, sub = vblock % bpt;
 		const uint32_t tile = p.tile_ids[tileNo];
-		tileNoOfBlock = tileNo;
+		res.tileNo = tileNo;
 		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
 		oldx = (tile % p.tiles_x) * p.tile_w + inx;
 		oldy = (tile / p.tiles_x) * p.tile_h + iny;
 		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
 	} else {
-		oldx = (blockIdx.x % p.blocks_x) * 16u + lx;
-		oldy = (blockIdx.x / p.blocks_x) * 16u + ly;
+		oldx = (vblock % p.blocks_x) * 16u + lx;
+		oldy = (vblock / p.blocks_x) * 16u + ly;
 		outSlot = 0;
 	}
 
-	Counters cnt = {0, 0, 0};
-	const bool active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
-	if (active) {
-		const int width = int(p.width), height = int(p.height);
-		const int oldIndex = int(oldx) + width * int(oldy);
-		int index;
-		if (p.frames == 0) { // renderer.cu:344-352
-			if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
-			index = oldIndex;
-		} else {
-			index = p.pixel_values ? p.pixel_values[oldIndex] : oldIndex;
+	Counters &cnt = res.cnt;
+	res.active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
+	if (!res.active)
+		return res;
+
+	const int width = int(p.width), height = int(p.height);
+	const int oldIndex = int(oldx) + width * int(oldy);
+	int index;
+	if (p.frames == 0) { // renderer.cu:344-352
+		if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
+		index = oldIndex;
+	} else {
+		index = p.pixel_values ? p.pixel_values[oldIndex] : oldIndex;
+	}
+	const int x = index % width;
+	const int y = index / width;
+	if (!tiled) outSlot = size_t(index);
+
+	RandState state;
+	randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
+
+	const float dx = 1.0f / width;
+	const float dy = 1.0f / height;
+	const float i = 2.0f * (float(x) + randUniform(state)) * dx - 1.0f;
+	const float j = 2.0f * (float(y) + randUniform(state)) * dy - 1.0f;
+
+	Ray r;
+	r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+	r.d = getPixelDir(p, i, -j);
+
+	// rayColor<max_bounces>(r, Color3(1,1,1), ...)
+	vec3 source(1, 1, 1);
+	vec4 tail(0, 0, 0, 1);
+	uint32_t level = 0;
+	bool bail = false;
+	// stored early so that they need no registers later; a pixel that bails is written again by the list pass
+	if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
+	if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
+	for (;;) {
+		if (level == p.max_bounces) // rayColor<0> (renderer.cu:318-324)
+			break;
+		WorldHit info;
+		info.t = FLT_MAX;
+		info.material = 0;
+		info.prim = 0xFFFFFFFFu;
+		info.position = vec3(0, 0, 0);
+		info.normal = vec3(0, 0, 0);
+		if (level > 0) cnt.bounce++;
+		const bool hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+		if (FAST && bail) break;
+		if (!hit)
+			break; // renderer.cu:315
+		if (level == 0) {
+			if (p.primid) p.primid[outSlot] = info.prim;
+			if (p.hit_t) p.hit_t[outSlot] = info.t;
+			cnt.primaryHits++;
 		}
-		const int x = index % width;
-		const int y = index / width;
-		if (!tiled) outSlot = size_t(index);
+		// direct illum (renderer.cu:247-248); the material record is fetched after the shadow rays
+		const vec3 lightSum = lightPoint<FAST>(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh, bail);
+		if (FAST && bail) break;
+		const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
+		const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
+		const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
+		const float refractiveIndex = asF(m0.w);
+		const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
+		const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
+		const vec3 c = ambient + diffuse * lightSum;
 
-		RandState state;
-		randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
-
-		const float dx = 1.0f / width;
-		const float dy = 1.0f / height;
-		const float i = 2.0f * (float(x) + randUniform(state)) * dx - 1.0f;
-		const float j = 2.0f * (float(y) + randUniform(state)) * dy - 1.0f;
-
-		Ray r;
-		r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
-		r.d = getPixelDir(p, i, -j);
-
-		// rayColor<max_bounces>(r, Color3(1,1,1), ...)
-		vec3 source(1, 1, 1);
-		vec4 tail(0, 0, 0, 1);
-		uint32_t level = 0;
-		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
-		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
-		for (;;) {
-			if (level == p.max_bounces) // rayColor<0> (renderer.cu:318-324)
-				break;
-			WorldHit info;
-			info.t = FLT_MAX;
-			info.material = 0;
-			info.prim = 0xFFFFFFFFu;
-			info.position = vec3(0, 0, 0);
-			info.normal = vec3(0, 0, 0);
-			if (level > 0) cnt.bounce++;
-			if (!sceneIntersect<false>(mem, sc, r, info, 0.0f, undoScene, undoMesh))
-				break; // renderer.cu:315
-			if (level == 0) {
-				if (p.primid) p.primid[outSlot] = info.prim;
-				if (p.hit_t) p.hit_t[outSlot] = info.t;
-				cnt.primaryHits++;
-			}
-			// direct illum (renderer.cu:247-248); the material record is fetched after the shadow rays
-			const vec3 lightSum = lightPoint(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh);
-			const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
-			const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
-			const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
-			const float refractiveIndex = asF(m0.w);
-			const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
-			const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
-			const vec3 c = ambient + diffuse * lightSum;
-
-			// indirect illum.  nSource is uninitialised in the reference's
-			// translucent branch (renderer.cu:251,286-311); defined as `source` here.
-			vec3 nSource = source;
-			Ray nr;
-			nr.o = info.position;
-			nr.d = vec3(0, 0, 0);
-			const bool last = level + 1 == p.max_bounces; // the next level returns (0,0,0,1) whatever the ray
-			if (refractiveIndex == 0) {
-				const vec3 cd = source * diffuse;
-				const vec3 cs = source * specular;
-				const float Pd = compMax(cd) / compMax(source);
-				const float Ps = compMax(cs) / compMax(source);
-				const float P = randUniform(state);
-				if (P < Pd) {
-					if (!last) {
-						nSource = cd * (1 / Pd);
-						nr.d = randomHemi(info.normal, state);
-					}
-				} else if (P < Pd + Ps) {
-					if (!last) {
-						nSource = cs * (1 / Ps);
-						nr.d = reflect(r.d, info.normal);
-					}
-				} else {
-					tail = vec4(c, 1); // absorbed (renderer.cu:282)
-					break;
+		// indirect illum.  nSource is uninitialised in the reference's
+		// translucent branch (renderer.cu:251,286-311); defined as `source` here.
+		vec3 nSource = source;
+		Ray nr;
+		nr.o = info.position;
+		nr.d = vec3(0, 0, 0);
+		const bool last = level + 1 == p.max_bounces; // the next level returns (0,0,0,1) whatever the ray
+		if (refractiveIndex == 0) {
+			const vec3 cd = source * diffuse;
+			const vec3 cs = source * specular;
+			const float Pd = compMax(cd) / compMax(source);
+			const float Ps = compMax(cs) / compMax(source);
+			const float P = randUniform(state);
+			if (P < Pd) {
+				if (!last) {
+					nSource = cd * (1 / Pd);
+					nr.d = randomHemi(info.normal, state);
 				}
-			} else if (!last) {
-				float n1, n2;
-				vec3 norm = info.normal;
-				if (dot(r.d, norm) < 0) {
-					n1 = refractiveIndex;
-					n2 = 1;
-				} else {
-					n1 = 1;
-					n2 = refractiveIndex;
-					norm *= -1.0f;
+			} else if (P < Pd + Ps) {
+				if (!last) {
+					nSource = cs * (1 / Ps);
+					nr.d = reflect(r.d, info.normal);
 				}
-				const float R = rSchlick2(r.d, norm, n1, n2);
-				if (randUniform(state) >= R)
-					nr.d = refract(r.d, norm, n1 / n2);
-				else
-					nr.d = reflect(r.d, norm);
-			}
-			if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
-				tail = vec4(c, 1) + vec4(0, 0, 0, 1);
+			} else {
+				tail = vec4(c, 1); // absorbed (renderer.cu:282)
 				break;
 			}
-			// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
-			cstack[(3 * level + 0) * kBlock] = c.x;
-			cstack[(3 * level + 1) * kBlock] = c.y;
-			cstack[(3 * level + 2) * kBlock] = c.z;
-			level++;
-			r = nr;
-			source = nSource;
+		} else if (!last) {
+			float n1, n2;
+			vec3 norm = info.normal;
+			if (dot(r.d, norm) < 0) {
+				n1 = refractiveIndex;
+				n2 = 1;
+			} else {
+				n1 = 1;
+				n2 = refractiveIndex;
+				norm *= -1.0f;
+			}
+			const float R = rSchlick2(r.d, norm, n1, n2);
+			if (randUniform(state) >= R)
+				nr.d = refract(r.d, norm, n1 / n2);
+			else
+				nr.d = reflect(r.d, norm);
 		}
-		vec4 contribution = tail;
-		while (level > 0) {
-			level--;
-			const vec4 cl(cstack[(3 * level + 0) * kBlock], cstack[(3 * level + 1) * kBlock], cstack[(3 * level + 2) * kBlock], 1.0f);
-			contribution = cl + contribution;
+		if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
+			tail = vec4(c, 1) + vec4(0, 0, 0, 1);
+			break;
 		}
-
-		// average (renderer.cu:375-387)
-		float4 *px = p.screen + outSlot;
-		if (p.frames > 0) {
-			const float4 old = *px;
-			vec4 s(old.x, old.y, old.z, old.w);
-			s = s * (float(p.frames) / float(p.frames + 1));
-			s = s + (contribution / float(p.frames + 1));
-			*px = make_float4(s.x, s.y, s.z, s.w);
-		} else {
-			*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
-		}
+		// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
+		cstack[(3 * level + 0) * kBlock] = c.x;
+		cstack[(3 * level + 1) * kBlock] = c.y;
+		cstack[(3 * level + 2) * kBlock] = c.z;
+		level++;
+		r = nr;
+		source = nSource;
+	}
+	if (FAST && bail) {
+		// nothing of this pixel is kept: the six-plane pass renders it from the start
+		res.bail = true;
+		res.cnt = {0, 0, 0};
+		return res;
+	}
+	vec4 contribution = tail;
+	while (level > 0) {
+		level--;
+		const vec4 cl(cstack[(3 * level + 0) * kBlock], cstack[(3 * level + 1) * kBlock], cstack[(3 * level + 2) * kBlock], 1.0f);
+		contribution = cl + contribution;
 	}
 
-	if (tiled && (p.tile_rays || p.tile_cycles)) {
-		if (p.tile_rays) {
-			const uint32_t rays = waveSum((active ? 1u : 0u) + cnt.shadow + cnt.bounce);
-			if (lane == 0) atomicAdd(&p.tile_rays[tileNoOfBlock], rays);
-		}
-		if (p.tile_cycles && lane == 0)
-			atomicAdd(&p.tile_cycles[tileNoOfBlock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	// average (renderer.cu:375-387)
+	float4 *px = p.screen + outSlot;
+	if (p.frames > 0) {
+		const float4 old = *px;
+		vec4 s(old.x, old.y, old.z, old.w);
+		s = s * (float(p.frames) / float(p.frames + 1));
+		s = s + (contribution / float(p.frames + 1));
+		*px = make_float4(s.x, s.y, s.z, s.w);
+	} else {
+		*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
+	}
+	return res;
+}
+
+// Adds one wave's ray counts to the per-tile and per-launch counters.
+__device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotResult &res, uint32_t vblock)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool counted = res.active && !res.bail;
+	if (p.num_tiles != 0 && p.tile_rays) {
+		// a wave lies inside one 16x16 block, hence inside one tile
+		const uint32_t rays = waveSum((counted ? 1u : 0u) + res.cnt.shadow + res.cnt.bounce);
+		const uint32_t tileNo = __builtin_amdgcn_readfirstlane(res.tileNo);
+		if (lane == 0 && rays) atomicAdd(&p.tile_rays[tileNo], rays);
 	}
 	if (p.counters) {
-		const uint32_t act = waveSum(active ? 1u : 0u);
-		const uint32_t sh = waveSum(cnt.shadow), bo = waveSum(cnt.bounce), ph = waveSum(cnt.primaryHits);
-		if (lane == 0) {
-			unsigned long long *slot = p.counters + 4 * (blockIdx.x % kCounterSlots);
+		const uint32_t act = waveSum(counted ? 1u : 0u);
+		const uint32_t sh = waveSum(res.cnt.shadow), bo = waveSum(res.cnt.bounce), ph = waveSum(res.cnt.primaryHits);
+		if (lane == 0 && (act | sh | bo | ph)) {
+			unsigned long long *slot = p.counters + 4 * (vblock % kCounterSlots);
 			atomicAdd(&slot[0], (unsigned long long)act);
 			atomicAdd(&slot[1], (unsigned long long)sh);
 			atomicAdd(&slot[2], (unsigned long long)bo);
@@ -719,8 +898,74 @@ __global__ void __launch_bounds__(kBlock, 4) renderKernel(const RenderParams p)
 	}
 }
 
-// Scene::intersect for caller-supplied rays, one ray per work-item.
+// One work-item per pixel slot of the frame (or of the listed tiles).
+// FAST: interval traversal; pixels it cannot serve are appended to p.redo_list for renderListKernel.
+template <bool SMALL_LDS, bool LARGE_LDS, bool FAST>
+__global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES) renderKernel(const RenderParams p)
+{
+	const SceneHeader &sc = p.scene;
+	SceneMem<SMALL_LDS, LARGE_LDS> mem;
+	mem.g = p.blob;
+	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
+	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
+
+	const bool tiled = p.num_tiles != 0;
+	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
+	const SlotResult res = renderSlot<FAST>(p, mem, blockIdx.x, threadIdx.x);
+	if constexpr (FAST) {
+		if (res.bail) {
+			const uint32_t at = atomicAdd(p.redo_count, 1u);
+			p.redo_list[at] = blockIdx.x * kBlock + threadIdx.x;
+		}
+	}
+	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
+		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	reportCounts(p, res, blockIdx.x);
+}
+
+// Renders the pixel slots listed by a FAST launch with the six-plane traversal: a fixed small grid that
+// strides over the list (usually empty).  Also zeroes the counter the NEXT frame's FAST launch appends with.
 template <bool SMALL_LDS, bool LARGE_LDS>
+__global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
+{
+	const uint32_t count = *p.redo_count;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_count_next = 0;
+	if (count == 0) return;
+	const SceneHeader &sc = p.scene;
+	SceneMem<SMALL_LDS, LARGE_LDS> mem;
+	mem.g = p.blob;
+	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
+	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
+	for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
+		const uint32_t k = base + threadIdx.x;
+		SlotResult res;
+		res.active = false;
+		res.bail = false;
+		res.tileNo = 0;
+		res.cnt = {0, 0, 0};
+		uint32_t vblock = 0;
+		if (k < count) {
+			const uint32_t slot = p.redo_list[k];
+			vblock = slot / kBlock;
+			res = renderSlot<false>(p, mem, vblock, slot % kBlock);
+		}
+		// lanes of one wave may belong to different tiles and blocks here: count per lane
+		if (res.active) {
+			if (p.num_tiles != 0 && p.tile_rays) atomicAdd(&p.tile_rays[res.tileNo], 1u + res.cnt.shadow + res.cnt.bounce);
+			if (p.counters) {
+				unsigned long long *c = p.counters + 4 * (vblock % kCounterSlots);
+				atomicAdd(&c[0], 1ull);
+				atomicAdd(&c[1], (unsigned long long)res.cnt.shadow);
+				atomicAdd(&c[2], (unsigned long long)res.cnt.bounce);
+				atomicAdd(&c[3], (unsigned long long)res.cnt.primaryHits);
+			}
+		}
+	}
+}
+
+// Scene::intersect for caller-supplied rays, one ray per work-item.  FAST: interval traversal for the
+// rays that qualify, six-plane traversal for the others, in the same launch.
+template <bool SMALL_LDS, bool LARGE_LDS, bool FAST>
 __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 {
 	const SceneHeader &sc = p.scene;
@@ -729,8 +974,6 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
 	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
 	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
-	float *undoScene = ldsF + threadIdx.x;
-	float *undoMesh = undoScene + sc.scene_depth * kBlock;
 
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= p.n) return;
@@ -738,12 +981,26 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 	r.o = vec3(p.origins[3 * i], p.origins[3 * i + 1], p.origins[3 * i + 2]);
 	r.d = vec3(p.dirs[3 * i], p.dirs[3 * i + 1], p.dirs[3 * i + 2]);
 	WorldHit info;
-	info.t = p.tmax ? p.tmax[i] : FLT_MAX;
-	info.material = 0;
-	info.prim = 0xFFFFFFFFu;
-	info.position = vec3(0, 0, 0);
-	info.normal = vec3(0, 0, 0);
-	const bool h = sceneIntersect<false>(mem, sc, r, info, 0.0f, undoScene, undoMesh);
+	bool h = false, bail = !FAST;
+	if constexpr (FAST) {
+		info.t = p.tmax ? p.tmax[i] : FLT_MAX;
+		info.material = 0;
+		info.prim = 0xFFFFFFFFu;
+		info.position = vec3(0, 0, 0);
+		info.normal = vec3(0, 0, 0);
+		float *undoScene = ldsF + 2 * threadIdx.x;
+		h = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, undoScene, undoScene + 2 * sc.scene_depth * kBlock, bail);
+	}
+	if (bail) {
+		info.t = p.tmax ? p.tmax[i] : FLT_MAX;
+		info.material = 0;
+		info.prim = 0xFFFFFFFFu;
+		info.position = vec3(0, 0, 0);
+		info.normal = vec3(0, 0, 0);
+		bool unused = false;
+		float *undoScene = ldsF + threadIdx.x;
+		h = sceneIntersect<false, false>(mem, sc, r, info, 0.0f, undoScene, undoScene + sc.scene_depth * kBlock, unused);
+	}
 	p.hit[i] = h ? 1 : 0;
 	p.t[i] = info.t;
 	p.prim[i] = info.prim;
@@ -772,24 +1029,43 @@ __global__ void __launch_bounds__(kBlock) scatterTilesKernel(const float4 *__res
 
 // ---- launchers used by the C ABI implementation (acr_hip.cpp) --------------
 
-extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+namespace
+{
+	template <class P>
+	hipError_t launchWithLds(void (*k)(const P), const P &p, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+	{
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(k, dim3(grid), dim3(acr::dev::kBlock), ldsBytes, stream, p);
+		return hipGetLastError();
+	}
+} // namespace
+
+// fast != 0: interval traversal for the whole grid, then the six-plane list pass over whatever it handed back
+// (p->redo_* must be set).  fast == 0: six-plane traversal for the whole grid.
+extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
 {
 	using namespace acr::dev;
-	void (*k)(const RenderParams) = ldsMode == 2 ? renderKernel<true, true> : (ldsMode == 1 ? renderKernel<true, false> : renderKernel<false, false>);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	typedef void (*K)(const RenderParams);
+	if (!fast) {
+		K k = ldsMode == 2 ? renderKernel<true, true, false> : (ldsMode == 1 ? renderKernel<true, false, false> : renderKernel<false, false, false>);
+		return launchWithLds(k, *p, grid, ldsBytes, stream);
+	}
+	K k = ldsMode == 2 ? renderKernel<true, true, true> : (ldsMode == 1 ? renderKernel<true, false, true> : renderKernel<false, false, true>);
+	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), ldsBytes, stream, *p);
-	return hipGetLastError();
+	K kl = ldsMode == 2 ? renderListKernel<true, true> : (ldsMode == 1 ? renderListKernel<true, false> : renderListKernel<false, false>);
+	return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream);
 }
 
-extern "C" hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
 {
 	using namespace acr::dev;
-	void (*k)(const TraceParams) = ldsMode == 2 ? traceKernel<true, true> : (ldsMode == 1 ? traceKernel<true, false> : traceKernel<false, false>);
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), ldsBytes, stream, *p);
-	return hipGetLastError();
+	typedef void (*K)(const TraceParams);
+	K k;
+	if (fast) k = ldsMode == 2 ? traceKernel<true, true, true> : (ldsMode == 1 ? traceKernel<true, false, true> : traceKernel<false, false, true>);
+	else k = ldsMode == 2 ? traceKernel<true, true, false> : (ldsMode == 1 ? traceKernel<true, false, false> : traceKernel<false, false, false>);
+	return launchWithLds(k, *p, grid, ldsBytes, stream);
 }
 
 extern "C" hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,

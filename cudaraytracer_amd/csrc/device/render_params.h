@@ -37,7 +37,15 @@ namespace dev
 		uint32_t *tile_rays;          // device [num_tiles] or null
 		uint32_t *tile_cycles;        // device [num_tiles] or null
 		uint32_t lds_stack_slot;    // first LDS slot after the staged scene
+		// Pixels the interval-traversal launch cannot serve: their slot numbers (workgroup * 256 + work-item) are
+		// appended here and rendered by the six-plane list pass that follows in the stream.
+		uint32_t *redo_count;       // device: entries in redo_list (this frame)
+		uint32_t *redo_count_next;  // device: the counter the next frame will use; the list pass zeroes it
+		uint32_t *redo_list;        // device [grid * 256]
 	};
+
+	// workgroups of the list pass
+	constexpr uint32_t kRedoGrid = 64;
 
 	struct TraceParams
 	{
@@ -55,8 +63,8 @@ namespace dev
 } // namespace acr
 
 extern "C" {
-hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream);
-hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, uint32_t grid, size_t ldsBytes, hipStream_t stream);
+hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
+hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
                                         uint32_t width, uint32_t height, void *frame, hipStream_t stream);
 }

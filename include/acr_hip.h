@@ -46,6 +46,9 @@ extern "C" {
 
 #define ACR_PRIM_NONE          0xFFFFFFFFu
 
+#define ACR_TRAVERSAL_AUTO      0  /* interval form of the slab test where it is provably identical, six-plane form elsewhere */
+#define ACR_TRAVERSAL_SIX_PLANE 1  /* the slab test exactly as written (geometry.h:44-76) for every ray */
+
 typedef struct acr_hip_ctx acr_hip_ctx;
 
 /*
@@ -160,6 +163,8 @@ typedef struct acr_stats {
 	uint32_t lds_bytes;            /* dynamic LDS per workgroup of the last launch */
 	uint32_t scene_in_lds;         /* 2 whole scene staged in LDS, 1 only the small tables, 0 none */
 	uint32_t grid_blocks;
+	uint32_t interval_traversal;   /* 1 when the last launch used the interval form (ACR_TRAVERSAL_AUTO on a qualifying scene) */
+	uint32_t six_plane_pixels;     /* pixels of that launch which were handed to the six-plane pass (needs collect_stats) */
 } acr_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -176,6 +181,11 @@ const char *acr_hip_last_error(const acr_hip_ctx *ctx);
 int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream);
 int acr_hip_use_own_stream(acr_hip_ctx *ctx);
 int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at renderer.cu:422 */
+
+/* Chooses how BoundingBox::intersect (geometry.h:44-76) is evaluated during BIH traversal
+ * (bih.h:241-248).  Results are identical either way; ACR_TRAVERSAL_SIX_PLANE exists so that
+ * tests can check exactly that.  Default ACR_TRAVERSAL_AUTO. */
+int acr_hip_set_traversal(acr_hip_ctx *ctx, int mode);
 
 /* ---- scene, camera, buffers -------------------------------------------- */
 

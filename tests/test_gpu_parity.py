@@ -284,3 +284,68 @@ def test_spot_and_directional_lights(core, acr, orc, scene_data):
     assert np.array_equal(img[..., 3], ref["screen"][..., 3])
     lit = r.sum(axis=2) > 0
     assert 0.05 < lit.mean() < 0.9  # the cone lights part of the box, not all of it
+
+
+def test_interval_and_six_plane_traversal_agree(core, built):
+    """the interval form of the slab test (default) and the six-plane form as written in geometry.h:44-76
+    must give the same frame bit for bit; both equal the oracle"""
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 384, 216
+    ref = b.oracle.render(w, h, seed=21, frames=0, max_bounces=4)
+    try:
+        core.set_traversal(six_plane_only=True)
+        img6, pid6, ht6, st6 = render(core, w, h, seed=21, frames=0, max_bounces=4)
+        assert st6.interval_traversal == 0
+        assert_same(img6, pid6, ht6, st6, ref)
+    finally:
+        core.set_traversal(six_plane_only=False)
+    img, pid, ht, st = render(core, w, h, seed=21, frames=0, max_bounces=4)
+    assert st.interval_traversal == 1 and st.six_plane_pixels == 0
+    assert_same(img, pid, ht, st, ref)
+
+
+def test_pixels_handed_to_the_six_plane_pass(core, acr, orc, scene_data):
+    """An object squashed flat (scale 0 along one axis) has a singular transform: rays that reach it get
+    non-finite local rays, which the interval traversal must not touch.  Those pixels go through the list
+    pass; the frame still equals the oracle's, pixel for pixel, including tiles and ray counts."""
+    import copy
+    d = copy.deepcopy(scene_data["cornell-box-cycles"])
+    names = [n["name"] for n in d.nodes]
+    k = names.index("short_box")
+    m = np.array(d.nodes[k]["transform"], dtype=np.float32).reshape(4, 4)  # column-major: m[col][row]
+    m[2, :3] = 0.0  # third column: the image of the local z axis
+    d.nodes[k]["transform"] = [float(v) for v in m.reshape(-1)]
+    b = Built(acr, orc, d)
+    load(core, b)
+    w, h = 320, 180
+    ref = b.oracle.render(w, h, seed=3, frames=0, max_bounces=3)
+    img, pid, ht, st = render(core, w, h, seed=3, frames=0, max_bounces=3)
+    assert st.interval_traversal == 1
+    assert 0 < st.six_plane_pixels <= w * h
+    assert_same(img, pid, ht, st, ref)
+    # second frame on the same context: the alternate counter is in use and starts from zero
+    img2, pid2, ht2, st2 = render(core, w, h, seed=3, frames=0, max_bounces=3)
+    assert st2.six_plane_pixels == st.six_plane_pixels
+    assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+    # tile mode with per-tile ray counts
+    import torch
+    tw, th = 64, 16
+    tx, ty = (w + tw - 1) // tw, (h + th - 1) // th
+    ids = np.arange(tx * ty, dtype=np.uint32)[::-1].copy()
+    tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+    rays = torch.zeros(len(ids), dtype=torch.int32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        core.render(w, h, seed=3, frames=0, max_bounces=3, tile_ids=ids, tile_w=tw, tile_h=th,
+                    screen_dev=C.c_void_p(tiles.data_ptr()), tile_rays_dev=C.c_void_p(rays.data_ptr()))
+        core.sync()
+    finally:
+        core.use_own_stream()
+    c = ref["counters"]
+    assert int(rays.sum().item()) == c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for n, tid in enumerate(ids):
+        x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
+        ww, hh = min(tw, w - x0), min(th, h - y0)
+        assert np.array_equal(t[n, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))

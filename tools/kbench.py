@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Kernel experiment bench: times the render kernel of ONE build of libacr_hip.so and prints a digest of
+the frame it produces, so that variants of the kernel can be compared for speed and for identical output.
+
+    python tools/kbench.py [--lib path/to/libacr_hip.so] [--scene cornell-box-cycles] [--size 1920x1080]
+                           [--bounces 1] [--steps 100] [--soup N --depth D]
+
+One process per variant (the library is bound before anything else loads the default one).
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--scene", default="cornell-box-cycles")
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--bounces", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--soup", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--edge", type=float, default=0.01)
+    ap.add_argument("--aov", action="store_true", help="also write primitive ids and hit distances")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    w, h = (int(v) for v in args.size.split("x"))
+
+    from cudaraytracer_amd import _capi
+    if args.lib:
+        _capi._hip = _capi._bind(C.CDLL(os.path.abspath(args.lib), mode=C.RTLD_GLOBAL), _capi.HIP_SYMBOLS)
+    import cudaraytracer_amd as acr
+
+    t0 = time.perf_counter()
+    if args.soup:
+        from conftest import soup_data
+        data = soup_data(acr, args.soup, seed=1, edge=args.edge)
+        view, keep = data.pack()
+        scene = acr.Scene(import_view=view, mesh_bih_depth=args.depth)
+    else:
+        data = acr.ImportData.load(os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".json"))
+        view, keep = data.pack()
+        scene = acr.Scene(import_view=view)
+    t_build = time.perf_counter() - t0
+    core = acr.HipCore(0)
+    t0 = time.perf_counter()
+    core.upload_scene(scene.soa)
+    t_upload = time.perf_counter() - t0
+    core.set_camera(scene.camera)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    core.set_stream(stream.cuda_stream)
+    screen = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    prim = torch.zeros((h, w), dtype=torch.int32, device=dev) if args.aov else None
+    ht = torch.zeros((h, w), dtype=torch.float32, device=dev) if args.aov else None
+    kw = dict(screen_dev=C.c_void_p(screen.data_ptr()))
+    if args.aov:
+        kw.update(primid_dev=C.cast(prim.data_ptr(), _capi.c_u32_p), hit_t_dev=C.cast(ht.data_ptr(), _capi.c_float_p))
+
+    core.render(w, h, seed=777, frames=0, max_bounces=args.bounces, collect_stats=True, **kw)
+    st = core.read_stats()
+    torch.cuda.synchronize()
+    digest = hashlib.sha1(screen.cpu().numpy().tobytes()).hexdigest()[:16]
+    if args.aov:
+        digest += "/" + hashlib.sha1(prim.cpu().numpy().tobytes() + ht.cpu().numpy().tobytes()).hexdigest()[:16]
+    rays = st.rays_primary + st.rays_shadow + st.rays_bounce
+
+    for k in range(5):
+        core.render(w, h, seed=1000 + k, frames=0, max_bounces=args.bounces, **kw)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for k, (a, b) in enumerate(evs):
+        a.record()
+        core.render(w, h, seed=2000 + k, frames=0, max_bounces=args.bounces, **kw)
+        b.record()
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in evs])
+    out = dict(tag=args.tag or (args.lib or "default"), scene=("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
+               size=args.size, bounces=args.bounces, ms_mean=float(ms.mean()), ms_min=float(ms.min()), ms_median=float(np.median(ms)),
+               rays=int(rays), grays_per_s=rays / (float(np.median(ms)) * 1e-3) / 1e9, digest=digest,
+               lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
+    print(json.dumps(out), flush=True)
+    core.close()
+
+
+if __name__ == "__main__":
+    main()
