@@ -125,7 +125,7 @@ HIP_SYMBOLS = {
 
 HOST_SYMBOLS = {
     "acr_host_import_blend": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
-    "acr_host_import_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float]),
+    "acr_host_import_soup": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "acr_host_import_view": (C.POINTER(ImportScene), [C.c_void_p]),
     "acr_host_import_destroy": (None, [C.c_void_p]),
     "acr_host_scene_create": (C.c_void_p, [C.POINTER(ImportScene), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),

@@ -69,10 +69,10 @@ acr_host_import *acr_host_import_blend(const char *path, char *err, size_t err_l
 	return imp;
 }
 
-acr_host_import *acr_host_import_soup(uint32_t num_triangles, uint32_t seed, float edge)
+acr_host_import *acr_host_import_soup(uint32_t num_triangles, uint32_t seed, float edge, float extent)
 {
 	acr_host_import *imp = new acr_host_import();
-	makeSoup(num_triangles, seed, edge, imp->scene);
+	makeSoup(num_triangles, seed, edge, extent, imp->scene);
 	imp->view = imp->scene.view();
 	return imp;
 }

@@ -258,14 +258,18 @@ __device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &m
 __device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) { return tmin <= tmax && tmin < tcur && tmax > epsilon(); }
 
 // bih.h:209-299 on intervals.  `stack` is this lane's column: stack[level * kBlock].
+// Loop shape: an inner loop that only descends (a lane leaves it at a leaf, or when its traversal has
+// nothing left), then the leaf's items, then the pop.  Lanes of a wave therefore do their node steps
+// together and their item tests together instead of interleaving the two.
 template <class LoadNode, class Leaf, class TCur>
 __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, float2 *stack, Leaf leaf, TCur tcur)
 {
 	uint32_t idx = 0, level = 0, pending = 0;
 	float tminB = box.tmin, tmaxB = box.tmax;
 	for (;;) {
-		const uint4 n = loadNode(idx);
-		if ((n.w & kNodeLeafBit) == 0) {
+		uint4 n = loadNode(idx);
+		bool alive = true;
+		while ((n.w & kNodeLeafBit) == 0) {
 			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
 			const bool sg = sa.sign(axis);
 			const float tl = sa.plane(axis, asF(n.x)); // lBB.max[axis] = left  (bih.h:244)
@@ -292,13 +296,26 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 				else tmaxB = nearSideMax;
 				idx = 2 * idx + (hitL ? 1 : 2);
 				level++;
-				continue;
+			} else {
+				// neither child: resume at the deepest level whose right child is still waiting
+				if (pending == 0) {
+					alive = false;
+					break;
+				}
+				const uint32_t l = 31u - uint32_t(__clz(int(pending)));
+				pending &= ~(1u << l);
+				const float2 b = stack[l * kBlock];
+				tminB = b.x;
+				tmaxB = b.y;
+				idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2; // right child of this path's node on level l
+				level = l + 1;
 			}
-		} else {
-			if (leaf(n.z, n.w & kNodeEndMask))
-				return;
+			n = loadNode(idx);
 		}
-		// pop: the deepest level whose right child is still waiting
+		if (!alive)
+			return;
+		if (leaf(n.z, n.w & kNodeEndMask))
+			return;
 		if (pending == 0)
 			return;
 		const uint32_t l = 31u - uint32_t(__clz(int(pending)));
@@ -306,7 +323,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 		const float2 b = stack[l * kBlock];
 		tminB = b.x;
 		tmaxB = b.y;
-		idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2; // right child of this path's node on level l
+		idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2;
 		level = l + 1;
 	}
 }

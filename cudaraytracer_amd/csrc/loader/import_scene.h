@@ -40,7 +40,7 @@ namespace acr
 	// Blender .blend -> ImportScene (loader/blend_import.cpp)
 	bool loadBlend(const char *path, ImportScene &out, std::string &error);
 	// procedural triangle soup (loader/procedural.cpp)
-	void makeSoup(uint32_t numTriangles, uint32_t seed, float edge, ImportScene &out);
+	void makeSoup(uint32_t numTriangles, uint32_t seed, float edge, float extent, ImportScene &out);
 } // namespace acr
 
 #endif

@@ -1,5 +1,10 @@
 // Procedural scenes.  makeSoup builds the deep-BIH stress workload: a cloud
-// of small independent triangles, one mesh, one object.  Every value comes
+// of small independent triangles (centres uniform in [-extent, extent]^3, edge
+// vectors uniform in [-edge, edge]^3), one mesh, one object, camera on the z
+// axis at 4 * extent, point light at 3 * extent.  The reference's triangle test
+// rejects |det| < 0.001 in absolute terms (math.h:140), so a soup only renders
+// when edge^2 is well above that: scale the cloud up rather than the triangles
+// down.  Every value comes
 // from a counter-based hash of (seed, triangle, component), so the scene is
 // reproducible anywhere and can be generated in any order.
 #include <cmath>
@@ -33,14 +38,14 @@ namespace acr
 		}
 	} // namespace
 
-	void makeSoup(uint32_t numTriangles, uint32_t seed, float edge, ImportScene &out)
+	void makeSoup(uint32_t numTriangles, uint32_t seed, float edge, float extent, ImportScene &out)
 	{
 		out = ImportScene();
 		out.positions.resize(9 * size_t(numTriangles));
 		out.normals.resize(9 * size_t(numTriangles));
 		out.indices.resize(3 * size_t(numTriangles));
 		for (uint64_t t = 0; t < numTriangles; t++) {
-			const math::vec3 c(unit(seed, t, 0), unit(seed, t, 1), unit(seed, t, 2));
+			const math::vec3 c = math::vec3(unit(seed, t, 0), unit(seed, t, 1), unit(seed, t, 2)) * extent;
 			const math::vec3 e1 = math::vec3(unit(seed, t, 3), unit(seed, t, 4), unit(seed, t, 5)) * edge;
 			const math::vec3 e2 = math::vec3(unit(seed, t, 6), unit(seed, t, 7), unit(seed, t, 8)) * edge;
 			const math::vec3 p[3] = {c, c + e1, c + e2};
@@ -82,7 +87,7 @@ namespace acr
 		acr_import_node lamp{};
 		lamp.parent = 0;
 		std::memcpy(lamp.transform, ident, sizeof(ident));
-		lamp.transform[14] = 3.0f; // translation z
+		lamp.transform[14] = 3.0f * extent; // translation z
 		setName(lamp.name, "Lamp");
 		out.nodes.push_back(lamp);
 		acr_import_light l{};
@@ -96,7 +101,7 @@ namespace acr
 		acr_import_node cam{};
 		cam.parent = 0;
 		std::memcpy(cam.transform, ident, sizeof(ident));
-		cam.transform[14] = 4.0f;
+		cam.transform[14] = 4.0f * extent;
 		setName(cam.name, "Camera");
 		out.nodes.push_back(cam);
 		setName(out.camera.name, "Camera");

@@ -78,10 +78,12 @@ typedef struct acr_host_import acr_host_import;
  * identical vertices).  err receives a message on failure. */
 acr_host_import *acr_host_import_blend(const char *path, char *err, size_t err_len);
 /* Procedural triangle soup: num_triangles small triangles with centres
- * uniform in [-1,1]^3 and edge vectors uniform in [-edge,edge]^3, one mesh,
- * one object, one material, one point light, camera on +z looking at the
- * origin.  Deterministic in (num_triangles, seed, edge). */
-acr_host_import *acr_host_import_soup(uint32_t num_triangles, uint32_t seed, float edge);
+ * uniform in [-extent,extent]^3 and edge vectors uniform in [-edge,edge]^3,
+ * one mesh, one object, one material, one point light at z = 3 * extent,
+ * camera at z = 4 * extent looking at the origin.  Deterministic in
+ * (num_triangles, seed, edge, extent).  The reference's triangle test drops
+ * triangles with |det| < 0.001 (math.h:140), i.e. roughly edge^2 < 0.001. */
+acr_host_import *acr_host_import_soup(uint32_t num_triangles, uint32_t seed, float edge, float extent);
 const acr_import_scene *acr_host_import_view(const acr_host_import *imp);
 void acr_host_import_destroy(acr_host_import *imp);
 

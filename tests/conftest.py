@@ -56,12 +56,12 @@ def built(acr, orc, scene_data):
     return {n: Built(acr, orc, d) for n, d in scene_data.items()}
 
 
-def soup_data(acr, ntri, seed=1, edge=0.05):
+def soup_data(acr, ntri, seed=1, edge=0.05, extent=1.0):
     """Procedural triangle soup as ImportData (through the product's generator)."""
     import ctypes as C
     from cudaraytracer_amd import _capi
     lib = _capi.host_lib()
-    h = lib.acr_host_import_soup(ntri, seed, C.c_float(edge))
+    h = lib.acr_host_import_soup(ntri, seed, C.c_float(edge), C.c_float(extent))
     try:
         return acr.ImportData.from_view(lib.acr_host_import_view(h).contents)
     finally:

@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--soup", type=int, default=0)
     ap.add_argument("--depth", type=int, default=6)
-    ap.add_argument("--edge", type=float, default=0.01)
+    ap.add_argument("--edge", type=float, default=0.1)
+    ap.add_argument("--extent", type=float, default=10.0)
     ap.add_argument("--aov", action="store_true", help="also write primitive ids and hit distances")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
@@ -46,7 +47,7 @@ def main():
     t0 = time.perf_counter()
     if args.soup:
         from conftest import soup_data
-        data = soup_data(acr, args.soup, seed=1, edge=args.edge)
+        data = soup_data(acr, args.soup, seed=1, edge=args.edge, extent=args.extent)
         view, keep = data.pack()
         scene = acr.Scene(import_view=view, mesh_bih_depth=args.depth)
     else:
