@@ -2,7 +2,7 @@
 """Headline benchmark: Mrays/s and ms/frame on the Cornell box at 1920x1080,
 primary + shadow rays (max_bounces = 1), on N MI355X GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
 
 N = 1 runs in-process.  N > 1 expects to be launched once per GPU by
 torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
@@ -14,8 +14,13 @@ after every camera move).  Rank 0 prints one JSON line.  On one GPU the line
 also carries the roofline of the render kernel (timed with HIP events on the
 stream it is launched on) and a CPU baseline: the oracle (this repository's
 CPU restatement of the reference algorithm) timed on the host cores on a
-bounded sample of the same workload, which doubles as a parity check of one
-frame.
+bounded sample of the same workload, which doubles as a parity check.
+
+Workloads (the default, c2, is the one the headline metric is quoted on):
+  c2  cornell-box-cycles 1920x1080, primary + shadow rays
+  c3  cornell-box-cycles 3840x2160, max_bounces 4
+  c4  procedural soup of 10 M triangles (mesh BIH depth 22), 1920x1080, primary + shadow rays
+  c5  c2 along a 120-frame camera flythrough (one camera per step, assignment rebalanced every frame)
 """
 import argparse
 import ctypes as C
@@ -32,33 +37,62 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import cudaraytracer_amd as acr  # noqa: E402
+from cudaraytracer_amd import _capi  # noqa: E402
+from cudaraytracer_amd import camera_path  # noqa: E402
 from cudaraytracer_amd import distributed as D  # noqa: E402
 
-WIDTH, HEIGHT, MAX_BOUNCES = 1920, 1080, 1
-SCENE = "cornell-box-cycles"
 TILE_W, TILE_H = 64, 16
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
-BYTES_PER_PIXEL = 16         # one float4 framebuffer write per pixel: the path's only compulsory HBM traffic
+BYTES_PER_PIXEL = 16         # one float4 framebuffer write per pixel
+NODE_BYTES, TRIANGLE_BYTES = 20, 36   # reference record sizes: BIH node (bih.h:92-98), three vertex positions
+
+WORKLOADS = {
+    "c2": dict(scene="cornell-box-cycles", width=1920, height=1080, bounces=1,
+               text="C2: cornell-box-cycles 1920x1080, primary + shadow rays (max_bounces 1), frames=0 every step"),
+    "c3": dict(scene="cornell-box-cycles", width=3840, height=2160, bounces=4,
+               text="C3: cornell-box-cycles 3840x2160, max_bounces 4, frames=0 every step"),
+    "c4": dict(soup=10_000_000, depth=22, edge=0.1, extent=10.0, width=1920, height=1080, bounces=1,
+               text="C4: procedural soup, 10 M triangles (centres in [-10,10]^3, edges in [-0.1,0.1]^3, seed 1), mesh BIH depth 22, "
+                    "1920x1080, primary + shadow rays"),
+    "c5": dict(scene="cornell-box-cycles", width=1920, height=1080, bounces=1, flythrough=120,
+               text="C5: cornell-box-cycles 1920x1080, primary + shadow rays, 120-frame camera flythrough (+-30 degrees), one camera per step"),
+}
 
 
-def algorithmic_flops(c):
+def algorithmic_flops(c, lights):
     """Arithmetic the reference algorithm performs for the counted work: slab test 12 flop, mesh box test
     3 divides on top, object entry 56, object hit exit 65, triangle test 53, direct-light term 30 per light
     and shaded hit, primary-ray generation 60."""
-    lights = 2
     return (12 * c["slab_tests"] + 3 * c["mesh_visits"] + 56 * c["object_visits"] + 65 * c["object_hits"] +
             53 * c["triangle_tests"] + 30 * lights * c["primary_hits"] + 60 * c["rays_primary"])
+
+
+def soup_import(n, edge, extent):
+    lib = _capi.host_lib()
+    h = lib.acr_host_import_soup(n, 1, C.c_float(edge), C.c_float(extent))
+    try:
+        return acr.ImportData.from_view(lib.acr_host_import_view(h).contents)
+    finally:
+        lib.acr_host_import_destroy(h)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    WIDTH, HEIGHT, MAX_BOUNCES = wl["width"], wl["height"], wl["bounces"]
+    heavy = args.workload in ("c3", "c4")
+    if args.steps is None:
+        args.steps = 30 if heavy else 200
+    if args.warmup is None:
+        args.warmup = 3 if heavy else 20
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,12 +116,23 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    data = acr.ImportData.load(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".json"))
-    view, keep = data.pack()
-    scene = acr.Scene(import_view=view)
+    if "soup" in wl:
+        data = soup_import(wl["soup"], wl["edge"], wl["extent"])
+        view, keep = data.pack()
+        scene = acr.Scene(import_view=view, mesh_bih_depth=wl["depth"])
+        scene_depths = (6, wl["depth"])
+        data_text = "procedural scene from the host library's generator (seed 1), one jitter seed per frame"
+    else:
+        data = acr.ImportData.load(os.path.join(ROOT, "tests", "golden", "scenes", wl["scene"] + ".json"))
+        view, keep = data.pack()
+        scene = acr.Scene(import_view=view)
+        scene_depths = (6, 6)
+        data_text = "reference scene %s (decoded fixture in tests/golden/scenes), one jitter seed per frame" % wl["scene"]
+    num_lights = scene.soa.num_lights
     core = acr.HipCore(local_rank)
     core.upload_scene(scene.soa)
     core.set_camera(scene.camera)
+    cameras = camera_path.flythrough(scene.camera, wl["flythrough"]) if "flythrough" in wl else None
     # one explicit stream for kernels, torch events and RCCL ordering
     stream = torch.cuda.Stream(device)
     torch.cuda.set_stream(stream)
@@ -95,6 +140,9 @@ def main():
 
     seed0 = 12345
     step_no = [0]
+
+    def camera_of(step):
+        return cameras[step % len(cameras)] if cameras else scene.camera
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,6 +156,8 @@ def main():
         ptr = C.c_void_p(screen.data_ptr())
 
         def step():
+            if cameras:
+                core.set_camera(camera_of(step_no[0]))
             core.render(WIDTH, HEIGHT, seed=seed0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr)
             step_no[0] += 1
 
@@ -127,18 +177,22 @@ def main():
         # rays of the timed frames, counted afterwards so that the timed launches carry no instrumentation
         rays = 0
         for k in range(args.steps):
+            if cameras:
+                core.set_camera(camera_of(first_timed + k))
             core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr, collect_stats=True)
             st = core.read_stats()
             rays += st.rays_primary + st.rays_shadow + st.rays_bounce
-        lds_bytes, lds_mode = st.lds_bytes, st.scene_in_lds
+        lds_bytes, lds_mode, interval = st.lds_bytes, st.scene_in_lds, st.interval_traversal
     else:
         def frame_args():
+            if cameras:
+                core.set_camera(camera_of(step_no[0]))
             a = dict(seed=seed0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES)
             step_no[0] += 1
             return a
         dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
-                                   rebalance_every=16, stage_through_host=rehearsal)
+                                   rebalance_every=1 if cameras else 16, stage_through_host=rehearsal)
         ray_sums = []
         for _ in range(args.warmup):
             dr.render_frame()
@@ -154,12 +208,12 @@ def main():
             local = local.cpu()
         dist.all_reduce(local)  # each rank counted the rays of its own tiles
         rays = int(local.item())
-        lds_bytes = lds_mode = None
         if rank == 0 and os.environ.get("ACR_BENCH_CHECK") == "1":
             # functional check of the assembled frame against a single full-frame render of the same seed
-            last_seed = seed0 + step_no[0] - 1
+            last = step_no[0] - 1
             full = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=device)
-            core.render(WIDTH, HEIGHT, seed=last_seed, frames=0, max_bounces=MAX_BOUNCES, screen_dev=C.c_void_p(full.data_ptr()))
+            core.set_camera(camera_of(last))
+            core.render(WIDTH, HEIGHT, seed=seed0 + last, frames=0, max_bounces=MAX_BOUNCES, screen_dev=C.c_void_p(full.data_ptr()))
             torch.cuda.synchronize()
             same = bool(torch.equal(full.view(torch.int32), dr.frame.view(torch.int32)))
             print(f"[check] assembled frame equals single-GPU frame: {same}; split {[int(x) for x in dr.plan.begin]}", file=sys.stderr)
@@ -187,60 +241,105 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "reference scene cornell-box-cycles (decoded fixture in tests/golden/scenes), one jitter seed per frame",
-            "config": {"workload": "C2: cornell-box-cycles 1920x1080, primary + shadow rays (max_bounces 1), frames=0 every step",
-                       "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
-                       "parallelism": "single GPU, full frame" if world == 1 else f"{TILE_W}x{TILE_H} tiles over {world} GPUs, cost-balanced Z-curve runs, RCCL gather to rank 0"},
+            "data": data_text,
+            "config": {"workload": wl["text"], "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
+                       "parallelism": "single GPU, full frame" if world == 1 else
+                       f"{TILE_W}x{TILE_H} tiles over {world} GPUs, cost-balanced Z-curve runs, RCCL gather to rank 0"},
         }
         if world == 1:
-            achieved = BYTES_PER_PIXEL * WIDTH * HEIGHT / (kernel_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "renderKernel<true,true>", "kernel_ms": kernel_ms,
-                               "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * WIDTH * HEIGHT,
-                               "note": "scene staged in LDS (%d B per workgroup, mode %d); the kernel is VALU/latency-bound, see roofline_valu" % (lds_bytes, lds_mode)}
+            kernel = "renderKernel<%s,%s,%s>" % ("true" if lds_mode >= 1 else "false", "true" if lds_mode == 2 else "false",
+                                                 "true" if interval else "false")
+            frame_bytes = BYTES_PER_PIXEL * WIDTH * HEIGHT
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": frame_bytes,
+                    "note": "LDS per workgroup %d B, staging mode %d (2 = whole scene resident in LDS, 1 = small tables only)" % (lds_bytes, lds_mode)}
+            # HBM bytes per launch measured with rocprofv3 counter passes of this same command, when a summary is committed
+            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = tj.get("source")
+            out["roofline"] = roof
             if not args.no_cpu_baseline:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import oracle  # CPU checker and reported baseline; never part of the timed GPU path
-                o = oracle.OracleScene(view)
+                o = oracle.OracleScene(view, *scene_depths)
                 threads = min(16, os.cpu_count() or 1)
-                frames, cpu_rays, t_cpu, counters = 0, 0, 0.0, None
-                while t_cpu < args.cpu_seconds:
+                cam0 = None
+                if cameras:
+                    cam0 = oracle.OrcCamera()
+                    C.memmove(C.byref(cam0), C.byref(camera_of(0)), C.sizeof(cam0))
+                    core.set_camera(camera_of(0))
+                # bounded sample: whole frames while they are cheap, else a band of rows in the middle of the frame
+                t_probe = None
+                for _ in range(2):  # the first pass also pages the scene in; the second one is the estimate
                     tc = time.perf_counter()
-                    r = o.render(WIDTH, HEIGHT, seed=seed0 + frames, frames=0, max_bounces=MAX_BOUNCES, threads=threads, aov=(frames == 0))
-                    t_cpu += time.perf_counter() - tc
-                    c = r["counters"]
-                    cpu_rays += c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
-                    if frames == 0:
-                        counters, ref = c, r
-                    frames += 1
+                    o.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=threads, aov=False, camera=cam0,
+                             row_begin=HEIGHT // 2 - 16, row_end=HEIGHT // 2 + 16)
+                    t_probe = time.perf_counter() - tc
+                rows_affordable = int(32 * args.cpu_seconds / max(t_probe, 1e-4))
+                whole = rows_affordable >= HEIGHT
+                frames_done, cpu_rays, t_cpu, counters, ref = 0, 0, 0.0, None, None
+                if whole:
+                    r0, r1 = 0, HEIGHT
+                    while t_cpu < args.cpu_seconds:
+                        tc = time.perf_counter()
+                        r = o.render(WIDTH, HEIGHT, seed=seed0 + frames_done, frames=0, max_bounces=MAX_BOUNCES, threads=threads,
+                                     aov=(frames_done == 0), camera=cam0)
+                        t_cpu += time.perf_counter() - tc
+                        c = r["counters"]
+                        cpu_rays += c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+                        if frames_done == 0:
+                            counters, ref = c, r
+                        frames_done += 1
+                    sample = f"{frames_done} frames of the same workload ({t_cpu:.1f} s)"
+                else:
+                    nrows = max(4, min(HEIGHT, rows_affordable) // 4 * 4)
+                    r0 = (HEIGHT - nrows) // 2
+                    r1 = r0 + nrows
+                    tc = time.perf_counter()
+                    ref = o.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=threads, aov=True, camera=cam0,
+                                   row_begin=r0, row_end=r1)
+                    t_cpu = time.perf_counter() - tc
+                    counters = ref["counters"]
+                    cpu_rays = counters["rays_primary"] + counters["rays_shadow"] + counters["rays_bounce"]
+                    sample = f"rows {r0}..{r1 - 1} of one {WIDTH}x{HEIGHT} frame of the same workload ({t_cpu:.1f} s)"
                 tc = time.perf_counter()
-                r1 = o.render(WIDTH, HEIGHT // 4, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=1, aov=False)["counters"]
+                rr = max(1, (r1 - r0) // 16)
+                c1 = o.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=1, aov=False, camera=cam0,
+                              row_begin=r0, row_end=r0 + rr)["counters"]
                 t1 = time.perf_counter() - tc
                 out["cpu_baseline"] = {"value": cpu_rays / t_cpu / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-                                       "sample": f"{frames} frames of the same workload ({t_cpu:.1f} s)",
-                                       "ms_per_frame": 1e3 * t_cpu / frames,
-                                       "value_1core": (r1["rays_primary"] + r1["rays_shadow"]) / t1 / 1e6,
+                                       "sample": sample, "value_1core": (c1["rays_primary"] + c1["rays_shadow"] + c1["rays_bounce"]) / t1 / 1e6,
                                        "host_cpus": os.cpu_count()}
-                # VALU-side roofline from the oracle's work counters of frame seed0
-                fl = algorithmic_flops(counters)
+                # algorithmic work per ray from the oracle's counters of the sample
                 rays0 = counters["rays_primary"] + counters["rays_shadow"] + counters["rays_bounce"]
-                tf = fl / (kernel_ms * 1e-3) / 1e12
+                fl = algorithmic_flops(counters, num_lights)
+                tf = fl / rays0 * (rays / args.steps) / (kernel_ms * 1e-3) / 1e12
                 out["roofline_valu"] = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "algorithmic_flops_per_ray": fl / rays0}
-                # parity of one frame: GPU vs oracle, every pixel
+                if lds_mode != 2:
+                    # nodes and triangles are read from HBM: count them at the reference's record sizes
+                    per_ray = (NODE_BYTES * counters["node_visits"] + TRIANGLE_BYTES * counters["triangle_tests"]) / rays0
+                    roof["algorithmic_bytes_per_ray"] = per_ray
+                    roof["algorithmic_bytes_per_launch"] = frame_bytes + per_ray * rays / args.steps
+                # parity: GPU vs oracle on the sampled rows, every pixel
                 core.resize(WIDTH, HEIGHT)
                 core.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES)
                 core.sync()
-                img, pid = core.read_framebuffer(), core.read_primid()
-                diff = img[..., :3].astype(np.float64) - ref["screen"][..., :3]
+                img, pid = core.read_framebuffer()[r0:r1], core.read_primid()[r0:r1]
+                rs, rp = ref["screen"][r0:r1], ref["prim"].reshape(HEIGHT, WIDTH)[r0:r1]
+                diff = img[..., :3].astype(np.float64) - rs[..., :3]
                 mse = float(np.mean(diff ** 2))
-                denom = np.maximum(np.abs(ref["screen"][..., :3]), 1e-6)
-                out["parity"] = {"primid_mismatches": int((pid != ref["prim"]).sum()),
-                                 "rgba_bit_mismatches": int((img.view(np.uint32) != ref["screen"].view(np.uint32)).sum()),
+                denom = np.maximum(np.abs(rs[..., :3]), 1e-6)
+                out["parity"] = {"rows": [r0, r1], "primid_mismatches": int((pid != rp).sum()),
+                                 "rgba_bit_mismatches": int((img.view(np.uint32) != rs.view(np.uint32)).sum()),
                                  "max_rel_err": float(np.max(np.abs(diff) / denom)),
                                  "psnr_db": None if mse == 0 else float(10 * np.log10(1.0 / mse)),
                                  "psnr_note": "null means identical images (infinite PSNR)"}
+            roof["achieved"] = roof["algorithmic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         print(json.dumps(out), flush=True)
 
     core.close()

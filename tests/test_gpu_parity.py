@@ -349,3 +349,85 @@ def test_pixels_handed_to_the_six_plane_pass(core, acr, orc, scene_data):
         x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
         ww, hh = min(tw, w - x0), min(th, h - y0)
         assert np.array_equal(t[n, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))
+
+
+def test_flythrough_cameras(core, built):
+    """frames of the 120-frame camera flythrough (every frame renders with frames = 0, as after moveCamera)"""
+    from cudaraytracer_amd import camera_path
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    cams = camera_path.flythrough(b.scene.camera, 120)
+    assert len(cams) == 120
+    w, h = 240, 135
+    try:
+        for k in (0, 37, 119):
+            core.set_camera(cams[k])
+            img, pid, ht, st = render(core, w, h, seed=500 + k, frames=0, max_bounces=2)
+            oc = orc_camera(cams[k])
+            assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=500 + k, frames=0, max_bounces=2, camera=oc))
+    finally:
+        core.set_camera(b.scene.camera)
+
+
+def orc_camera(cam):
+    import oracle
+    oc = oracle.OrcCamera()
+    C.memmove(C.byref(oc), C.byref(cam), C.sizeof(oc))
+    return oc
+
+
+def test_soup_10m_triangles_full_size(core, acr, orc):
+    """The deep-BIH workload at its full size: 10 M triangles, mesh BIH depth 22, 1920x1080.  The oracle is
+    compared on a band of rows (every pixel of the band); the whole frame is held to properties that do not
+    depend on size: both forms of the slab test give identical frames, a tile list reproduces the same
+    pixels, misses are exactly (0,0,0,1), ids and distances are in range, ray counts are consistent."""
+    w, h, depth = 1920, 1080, 22
+    data = soup_data(acr, 10_000_000, seed=1, edge=0.1, extent=10.0)
+    view, keep = data.pack()
+    scene = acr.Scene(import_view=view, mesh_bih_depth=depth)
+    core.upload_scene(scene.soa)
+    core.set_camera(scene.camera)
+    img, pid, ht, st = render(core, w, h, seed=9, frames=0, max_bounces=1)
+    assert st.scene_in_lds == 1 and st.interval_traversal == 1
+    miss = pid == 0xFFFFFFFF
+    assert 0.2 < (~miss).mean() < 0.9
+    assert np.all(ht[miss] == FMAX) and np.all(img[miss][:, :3] == 0) and np.all(img[miss][:, 3] == 1)
+    assert np.isin(img[~miss][:, 3], (1, 2)).all()  # absorbed at the hit, or continued into rayColor<0> (renderer.cu:282,312)
+    assert pid[~miss].max() < 10_000_000 and np.isfinite(ht[~miss]).all() and (ht[~miss] > 0).all()
+    assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
+    assert st.rays_primary == w * h and st.primary_hits == int((~miss).sum()) and 0 < st.rays_shadow <= st.primary_hits
+    # the slab test as written in the reference, for every ray
+    try:
+        core.set_traversal(six_plane_only=True)
+        img6, pid6, ht6, st6 = render(core, w, h, seed=9, frames=0, max_bounces=1)
+    finally:
+        core.set_traversal(six_plane_only=False)
+    assert st6.interval_traversal == 0
+    assert np.array_equal(pid6, pid) and np.array_equal(ht6.view(np.uint32), ht.view(np.uint32))
+    assert np.array_equal(img6.view(np.uint32), img.view(np.uint32))
+    assert (st6.rays_shadow, st6.primary_hits) == (st.rays_shadow, st.primary_hits)
+    # a band of rows against the oracle
+    o = orc.OracleScene(view, 6, depth)
+    r0, r1 = 536, 544
+    ref = o.render(w, h, seed=9, frames=0, max_bounces=1, row_begin=r0, row_end=r1)
+    assert np.array_equal(pid[r0:r1], ref["prim"][r0:r1])
+    assert np.array_equal(ht[r0:r1].view(np.uint32), ref["t"][r0:r1].view(np.uint32))
+    assert np.array_equal(img[r0:r1].view(np.uint32), ref["screen"][r0:r1].view(np.uint32))
+    o.close()
+    # tiles out of order give the same pixels
+    import torch
+    tw, th = 64, 16
+    tx = (w + tw - 1) // tw
+    ids = np.array([5 * tx + 3, 40 * tx + 29, 2, 67 * tx + 1], dtype=np.uint32)  # the last one is cut by the frame's bottom edge
+    tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        core.render(w, h, seed=9, frames=0, max_bounces=1, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
+        core.sync()
+    finally:
+        core.use_own_stream()
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for n, tid in enumerate(ids):
+        x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
+        ww, hh = min(tw, w - x0), min(th, h - y0)
+        assert np.array_equal(t[n, :hh, :ww].view(np.uint32), img[y0:y0 + hh, x0:x0 + ww].view(np.uint32))
