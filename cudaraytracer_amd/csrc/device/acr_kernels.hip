@@ -86,7 +86,7 @@ struct SlabArgs
 		sy = invD.y < 0;
 		sz = invD.z < 0;
 	}
-	__device__ __forceinline__ bool sign(uint32_t axis) const { return axis == 0 ? sx : (axis == 1 ? sy : sz); }
+	__device__ __forceinline__ bool sign(uint32_t axis) const { return invD[int(axis)] < 0; }
 	// (bound - o) * invD on one axis: the per-plane term of geometry.h:52-66
 	__device__ __forceinline__ float plane(uint32_t axis, float bound) const { return (bound - o[int(axis)]) * invD[int(axis)]; }
 };
@@ -271,9 +271,10 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 		bool alive = true;
 		while ((n.w & kNodeLeafBit) == 0) {
 			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
-			const bool sg = sa.sign(axis);
-			const float tl = sa.plane(axis, asF(n.x)); // lBB.max[axis] = left  (bih.h:244)
-			const float tr = sa.plane(axis, asF(n.y)); // rBB.min[axis] = right (bih.h:245)
+			const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
+			const bool sg = ia < 0;
+			const float tl = (asF(n.x) - oa) * ia; // lBB.max[axis] = left  (bih.h:244)
+			const float tr = (asF(n.y) - oa) * ia; // rBB.min[axis] = right (bih.h:245)
 			// The child on the ray's near side keeps the parent's tmin and is cut at its far plane;
 			// the other keeps the parent's tmax and is cut at its near plane.  Left is the near-side
 			// child for a positive direction.

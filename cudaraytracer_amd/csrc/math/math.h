@@ -39,7 +39,8 @@ namespace math
 		ACR_HD vec3() : x(0), y(0), z(0) {}
 		ACR_HD vec3(float a, float b, float c) : x(a), y(b), z(c) {}
 		ACR_HD explicit vec3(float s) : x(s), y(s), z(s) {}
-		ACR_HD float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+		// two selects in sequence (not nested): hipcc turns this shape into v_cndmask, the nested one into branches
+		ACR_HD float operator[](int i) const { const float xy = i == 1 ? y : x; return i == 2 ? z : xy; }
 		ACR_HD void set(int i, float v) { if (i == 0) x = v; else if (i == 1) y = v; else z = v; }
 	};
 
