@@ -5,7 +5,10 @@ trace, per-dispatch means of the counter passes, and the figures derived from
 them as MI355X_MICROARCH.md prescribes: SQ_* cycle counters are quad-cycles,
 FETCH_SIZE under-reports wide reads by 2x, GRBM_GUI_ACTIVE is summed over 8 XCDs).
 
-    python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name> [kernel-substring]
+    python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name> [kernel-substring] [workload]
+
+With a workload name (c2, c3, c4, c5) it also writes profiles/traffic_<workload>.json, the measured HBM
+bytes per launch that bench.py reports as roofline.traffic for that workload.
 """
 import collections
 import csv
@@ -87,6 +90,14 @@ def main():
         f.write("\n| counter (mean per dispatch) | value |\n|---|---|\n")
         for k, v in sorted(counters.items()):
             f.write(f"| {k} | {v:.6g} |\n")
+    if len(sys.argv) > 4 and "hbm_bytes" in d:
+        with open(os.path.join(os.path.dirname(dst) or ".", "traffic_%s.json" % sys.argv[4]), "w") as f:
+            json.dump({"workload": sys.argv[4], "hbm_bytes_per_launch": d["hbm_bytes"], "hbm_write_bytes": d["hbm_write_bytes"],
+                       "hbm_read_bytes": d["hbm_read_bytes_corrected_x2"], "kernel": out.get("kernel"), "kernel_avg_us": out["avg_ns"] / 1e3,
+                       "source": os.path.basename(dst) + ".json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as "
+                                 "prescribed for 16-byte-per-lane reads on gfx950)"}, f, indent=1)
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
     print(json.dumps(d, indent=1))
 
 
