@@ -41,7 +41,7 @@ from cudaraytracer_amd import _capi  # noqa: E402
 from cudaraytracer_amd import camera_path  # noqa: E402
 from cudaraytracer_amd import distributed as D  # noqa: E402
 
-TILE_W, TILE_H = 64, 16
+TILE_H = 16                  # multi-GPU: full-width bands of 16 rows (a rank's run of bands is contiguous in the frame)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 BYTES_PER_PIXEL = 16         # one float4 framebuffer write per pixel
@@ -190,6 +190,7 @@ def main():
             a = dict(seed=seed0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES)
             step_no[0] += 1
             return a
+        TILE_W = WIDTH
         dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
                                    rebalance_every=1 if cameras else 16, stage_through_host=rehearsal)
@@ -201,6 +202,7 @@ def main():
         for _ in range(args.steps):
             dr.render_frame()
             ray_sums.append(dr.rays_last_frame())  # device scalar, no sync
+        dr.finish()
         barrier()
         elapsed = time.perf_counter() - t0
         local = torch.stack(ray_sums).double().sum().reshape(1)
@@ -244,7 +246,7 @@ def main():
             "data": data_text,
             "config": {"workload": wl["text"], "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
                        "parallelism": "single GPU, full frame" if world == 1 else
-                       f"{TILE_W}x{TILE_H} tiles over {world} GPUs, cost-balanced Z-curve runs, RCCL gather to rank 0"},
+                       f"full-width bands of {TILE_H} rows over {world} GPUs, cost-balanced contiguous runs, received in place on rank 0 over RCCL, two frames in flight"},
         }
         if world == 1:
             kernel = "renderKernel<%s,%s,%s>" % ("true" if lds_mode >= 1 else "false", "true" if lds_mode == 2 else "false",

@@ -8,12 +8,12 @@ tiles and GPUs instead of pixels and threads: the work goes through an
 explicit table, the table is rebuilt from costs measured on earlier frames,
 and a camera move resets it to the uniform split (renderer.cu:165,344-348).
 
-Pixels are independent, so a frame needs no exchange while it renders.  Per
-frame there are two small steps over torch.distributed (RCCL on GPUs, gloo on
-CPU): an all-reduce of the per-tile cost vector (4 bytes per tile) so that
-every rank derives the same next assignment, and point-to-point sends of each
-rank's finished tiles to rank 0 (grouped isend/irecv: a gather with unequal
-counts; each sender has its own xGMI link to GPU 0).
+Pixels are independent, so a frame needs no exchange while it renders.  Over
+torch.distributed (RCCL on GPUs, gloo on CPU) there are two steps: per frame,
+point-to-point sends of each rank's finished piece to rank 0 (grouped
+isend/irecv: a gather with unequal counts; each sender has its own xGMI link to
+GPU 0); and, every `rebalance_every` frames, an all-reduce of the per-tile cost
+vector (4 bytes per tile) so that every rank derives the same next assignment.
 
 The renderer itself is passed in as a callable so that the same code runs on
 CPU ranks in tests:
@@ -71,7 +71,10 @@ class TiledFrame:
         self.tile_w, self.tile_h = tile_w, tile_h
         self.tiles_x, self.tiles_y = tile_grid(width, height, tile_w, tile_h)
         self.num_tiles = self.tiles_x * self.tiles_y
-        self.order = tile_order(self.tiles_x, self.tiles_y)
+        # full-width bands are visited top to bottom (a run of them is one contiguous piece of the frame);
+        # smaller tiles along a Z-curve (a run of them is a compact region)
+        self.bands = self.tiles_x == 1 and tile_w == width
+        self.order = np.arange(self.num_tiles, dtype=np.uint32) if self.bands else tile_order(self.tiles_x, self.tiles_y)
         self.cost = None           # per-tile cost of the last frame, indexed by tile id
         self.begin = partition(self.order, None, world_size)
 
@@ -92,20 +95,28 @@ class TiledFrame:
 class DistributedRenderer:
     """Renders frames across the ranks of the default process group and assembles them on rank 0.
 
-    All tile buffers are kept in Z-curve order.  The runs of the ranks, concatenated in rank order, are the
-    whole curve whatever the split, so rank 0 owns one buffer [num_tiles][tile pixels] float4: it renders its
-    own run straight into the front slice, receives rank r's run straight into slice [begin[r], begin[r+1])
-    (no staging copy), and one scatter with the fixed Z-order list writes the frame.  Per-tile costs live in
-    one [num_tiles] vector in the same order."""
+    Two layouts, chosen by the tile shape:
 
-    def __init__(self, width, height, render_tiles, device, tile_w=64, tile_h=16, scatter=None, rebalance_every=1,
-                 stage_through_host=False):
+    * bands (tile_w == width, the default when the width is a multiple of 16): a tile is a full-width band of
+      tile_h rows and a rank's run of bands is one contiguous piece of the frame.  Every rank renders straight
+      into frame-shaped memory, rank 0 receives each other rank's piece straight into the final frame: no
+      staging buffer and no scatter pass.  Frames are double-buffered and the exchange of frame k is only
+      waited for when its buffer comes up again, so it overlaps the rendering of frame k + 1.
+    * tiles (anything else): tile buffers are kept in Z-curve order; the runs of the ranks, concatenated in
+      rank order, are the whole curve whatever the split, so rank 0 owns one buffer [num_tiles][tile pixels]
+      float4, receives rank r's run into slice [begin[r], begin[r+1]) and one scatter writes the frame.
+
+    Per-tile costs live in one [num_tiles] vector in visiting order."""
+
+    def __init__(self, width, height, render_tiles, device, tile_w=None, tile_h=16, scatter=None, rebalance_every=1,
+                 stage_through_host=False, depth=2):
         """scatter(tiles, tile_ids, frame): writes compact tiles into the full frame tensor
-        [height, width, 4] on rank 0; None selects a torch implementation.
+        [height, width, 4] on rank 0; None selects a torch implementation (tiles layout only).
         rebalance_every: the assignment is rebuilt from the measured costs every this many frames (0 = never);
         the reference re-sorts its pixel table every 60 still frames (renderer.cu:392,457).
         stage_through_host: move tiles and costs through CPU tensors for the exchange (for a process group
-        whose backend cannot carry device tensors, e.g. gloo when rehearsing the multi-rank path on one GPU)."""
+        whose backend cannot carry device tensors, e.g. gloo when rehearsing the multi-rank path on one GPU).
+        depth: frame buffers in flight (bands layout)."""
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.device = device
@@ -113,20 +124,44 @@ class DistributedRenderer:
         self.scatter = scatter or self._scatter_torch
         self.rebalance_every = rebalance_every
         self.stage_through_host = stage_through_host
+        if tile_w is None:
+            tile_w = width if width % 16 == 0 else 64
         self.plan = TiledFrame(width, height, self.world, tile_w, tile_h)
         self.tile_px = tile_w * tile_h
-        self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if self.rank == 0 else None
+        self.width, self.height = width, height
         n = self.plan.num_tiles
-        # rank 0 holds every tile; the others only ever hold their own run (sized for the largest possible run)
-        self.tiles = torch.zeros((n, self.tile_px, 4), dtype=torch.float32, device=device)
-        self.cost = torch.zeros(n, dtype=torch.int32, device=device)  # Z-order; only this rank's run is ever non-zero
+        self.bands = self.plan.bands
+        self.depth = max(1, depth) if self.bands else 1
+        # bands: every rank renders into frame-shaped buffers (rank 0's are the assembled frames);
+        # tiles: rank 0 holds every tile, the others their own run (sized for the largest possible run)
+        self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=device)
+                       for _ in range(self.depth if self.bands else (1 if self.rank == 0 else 0))]
+        self.tiles = None if self.bands else torch.zeros((n, self.tile_px, 4), dtype=torch.float32, device=device)
+        self.cost = torch.zeros(n, dtype=torch.int32, device=device)  # visiting order; only this rank's run is ever non-zero
+        self.pending = [[] for _ in range(self.depth)]  # exchange handles still in flight, per frame buffer
+        self.frame_no = 0
         self.frames_since_rebalance = 0
         self.last_cost = self.cost
         self._rays_last = torch.zeros((), dtype=torch.int64, device=device)
 
+    @property
+    def frame(self):
+        """The buffer of the most recent frame on rank 0 (complete after finish())."""
+        if not self.frames:
+            return None
+        return self.frames[(self.frame_no - 1) % len(self.frames)] if self.frame_no else self.frames[0]
+
     def camera_moved(self):
         self.frames_since_rebalance = 0
         self.plan.reset()
+
+    def finish(self):
+        """Waits for every exchange still in flight; returns the most recent frame on rank 0."""
+        for slot in range(self.depth):
+            for w in self.pending[slot]:
+                w.wait()
+            self.pending[slot] = []
+        return self.frame if self.rank == 0 else None
 
     def _scatter_torch(self, tiles, tile_ids, frame):
         p = self.plan
@@ -136,39 +171,76 @@ class DistributedRenderer:
             w, h = min(p.tile_w, p.width - x0), min(p.tile_h, p.height - y0)
             frame[y0:y0 + h, x0:x0 + w] = t[k, :h, :w]
 
+    def _band_pixels(self, b0, b1):
+        """flat pixel range of bands [b0, b1) inside the frame (the last band may be cut by the frame's bottom edge)"""
+        return b0 * self.tile_px, min(b1 * self.tile_px, self.width * self.height)
+
     def render_frame(self):
-        """One frame.  Returns the assembled frame tensor on rank 0, None elsewhere."""
+        """One frame.  Returns the frame tensor on rank 0 (None elsewhere); with the bands layout its
+        exchange may still be in flight until finish() or until `depth` more frames were started."""
         p = self.plan
         b0, b1 = int(p.begin[self.rank]), int(p.begin[self.rank + 1])
-        # rank 0 keeps its run at its Z position; other ranks use the front of their buffer
-        at = b0 if self.rank == 0 else 0
-        out = self.tiles[at:at + (b1 - b0)]
         cost = self.cost[b0:b1]
-        if b1 > b0:
-            self.render_tiles(p.order[b0:b1], out, cost)
+        slot = self.frame_no % self.depth
+        for w in self.pending[slot]:  # this buffer's previous exchange must be over before it is overwritten
+            w.wait()
+        self.pending[slot] = []
 
-        if self.world > 1:
-            ops, staged = [], {}
+        if self.bands:
+            flat = self.frames[slot].view(-1, 4)
+            px0, px1 = self._band_pixels(b0, b1)
+            out = flat[px0:px1]
+            if b1 > b0:
+                self.render_tiles(p.order[b0:b1], out, cost)
+            if self.world > 1:
+                ops, staged = [], {}
+                if self.rank == 0:
+                    for r in range(1, self.world):
+                        q0, q1 = self._band_pixels(int(p.begin[r]), int(p.begin[r + 1]))
+                        if q1 > q0:
+                            dst = flat[q0:q1]
+                            if self.stage_through_host:
+                                staged[r] = (torch.empty(dst.shape, dtype=dst.dtype), dst)
+                                dst = staged[r][0]
+                            ops.append(dist.P2POp(dist.irecv, dst, r))
+                elif px1 > px0:
+                    ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
+                works = dist.batch_isend_irecv(ops) if ops else []
+                if staged:
+                    for w in works:
+                        w.wait()
+                    works = []
+                    for buf, dst in staged.values():
+                        dst.copy_(buf)
+                self.pending[slot] = works
+        else:
+            # rank 0 keeps its run at its Z position; other ranks use the front of their buffer
+            at = b0 if self.rank == 0 else 0
+            out = self.tiles[at:at + (b1 - b0)]
+            if b1 > b0:
+                self.render_tiles(p.order[b0:b1], out, cost)
+            if self.world > 1:
+                ops, staged = [], {}
+                if self.rank == 0:
+                    for r in range(1, self.world):
+                        rb0, rb1 = int(p.begin[r]), int(p.begin[r + 1])
+                        if rb1 > rb0:
+                            dst = self.tiles[rb0:rb1]
+                            if self.stage_through_host:
+                                staged[r] = torch.empty(dst.shape, dtype=dst.dtype)
+                                dst = staged[r]
+                            ops.append(dist.P2POp(dist.irecv, dst, r))
+                elif b1 > b0:
+                    ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
+                works = dist.batch_isend_irecv(ops) if ops else []
+                for w in works:
+                    w.wait()
+                for r, buf in staged.items():
+                    self.tiles[int(p.begin[r]):int(p.begin[r + 1])].copy_(buf)
             if self.rank == 0:
-                for r in range(1, self.world):
-                    rb0, rb1 = int(p.begin[r]), int(p.begin[r + 1])
-                    if rb1 > rb0:
-                        dst = self.tiles[rb0:rb1]
-                        if self.stage_through_host:
-                            staged[r] = torch.empty(dst.shape, dtype=dst.dtype)
-                            dst = staged[r]
-                        ops.append(dist.P2POp(dist.irecv, dst, r))
-            elif b1 > b0:
-                ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
-            works = dist.batch_isend_irecv(ops) if ops else []
-            for w in works:
-                w.wait()
-            for r, buf in staged.items():
-                self.tiles[int(p.begin[r]):int(p.begin[r + 1])].copy_(buf)
+                self.scatter(self.tiles, p.order, self.frames[0])
 
-        if self.rank == 0:
-            self.scatter(self.tiles, p.order, self.frame)
-
+        self.frame_no += 1
         self.last_cost = self.cost
         self._rays_last = cost.sum() if b1 > b0 else torch.zeros((), dtype=torch.int64, device=self.device)
         self.frames_since_rebalance += 1
@@ -179,13 +251,13 @@ class DistributedRenderer:
                 if self.stage_through_host:
                     full = full.cpu()
                 dist.all_reduce(full)  # every rank contributes its run; all ranks get the whole vector
-            cost_z = full.cpu().numpy()
+            cost_v = full.cpu().numpy()
             by_tile = np.zeros(p.num_tiles, dtype=np.float32)
-            by_tile[p.order] = cost_z
+            by_tile[p.order] = cost_v
             if b1 > b0:
                 self.cost[b0:b1].zero_()  # the next run may start elsewhere: leave no stale costs behind
             p.update(by_tile)
-        return self.frame
+        return self.frame if self.rank == 0 else None
 
     def rays_last_frame(self):
         """Device scalar: rays this rank traced in the last frame (sum of its per-tile costs when the cost is a ray count)."""

@@ -1,7 +1,9 @@
 """The multi-GPU frame assembly, rehearsed with two CPU processes over gloo:
 each rank renders its tiles (the oracle stands in for the GPU core here),
 rank 0 gathers and assembles, and the result must equal one full-frame render.
-Covers the uniform split, cost feedback and a camera-move reset."""
+Covers both layouts (Z-ordered tiles with a scatter pass; full-width bands
+received in place with two frames in flight), the uniform split, cost feedback
+and a camera-move reset."""
 import os
 import socket
 import sys
@@ -24,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, layout):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(HERE, ".."))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,23 +42,28 @@ def _worker(rank, world, port, out_path):
     state = dict(seed=21)
     rendered = []
 
+    tw = W if layout == "bands" else TW
+
     def render_tiles(tile_ids, out, cost):
-        # stand-in for the GPU core: render the frame on the CPU, cut out this rank's tiles
+        # stand-in for the GPU core: render the frame on the CPU, cut out this rank's tiles in the compact
+        # layout [tile][row][column] the kernel writes (`out` may end before the last tile's last rows)
         r = o.render(W, H, seed=state["seed"], frames=0, max_bounces=2, threads=2)
         img = r["screen"]
-        tiles_x = (W + TW - 1) // TW
-        buf = np.zeros((len(tile_ids), TH, TW, 4), np.float32)
+        tiles_x = (W + tw - 1) // tw
+        buf = np.zeros((len(tile_ids), TH, tw, 4), np.float32)
         c = np.zeros(len(tile_ids), np.float32)
         for k, t in enumerate(tile_ids):
-            x0, y0 = (int(t) % tiles_x) * TW, (int(t) // tiles_x) * TH
-            w, h = min(TW, W - x0), min(TH, H - y0)
+            x0, y0 = (int(t) % tiles_x) * tw, (int(t) // tiles_x) * TH
+            w, h = min(tw, W - x0), min(TH, H - y0)
             buf[k, :h, :w] = img[y0:y0 + h, x0:x0 + w]
             c[k] = 1.0 + float((r["prim"][y0:y0 + h, x0:x0 + w] != 0xFFFFFFFF).sum())
-        out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
+        flat = out.view(-1, 4)
+        flat.copy_(torch.from_numpy(buf.reshape(-1, 4)[:flat.shape[0]]))
         cost.copy_(torch.from_numpy(c.astype(np.int32)))
         rendered.append(len(tile_ids))
 
-    dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
+    dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=tw, tile_h=TH)
+    assert dr.bands == (layout == "bands")
     results = {}
     splits = []
     for step, seed in enumerate((21, 22, 23)):
@@ -64,10 +71,23 @@ def _worker(rank, world, port, out_path):
         if step == 2:
             dr.camera_moved()  # back to the uniform split
         splits.append([int(x) for x in dr.plan.begin])
-        frame = dr.render_frame()
+        dr.render_frame()
+        frame = dr.finish()
         if rank == 0:
             ref = o.render(W, H, seed=seed, frames=0, max_bounces=2, threads=2)["screen"]
             results[f"equal{step}"] = bool(np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32)))
+    # frames started back to back: the exchange of one frame is still in flight while the next one renders
+    for seed in (31, 32, 33):
+        state["seed"] = seed
+        dr.render_frame()
+    frame = dr.finish()
+    if rank == 0:
+        ref = o.render(W, H, seed=33, frames=0, max_bounces=2, threads=2)["screen"]
+        results["equal_pipelined"] = bool(np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32)))
+        if dr.depth > 1:
+            prev = dr.frames[(dr.frame_no - 2) % dr.depth]
+            ref = o.render(W, H, seed=32, frames=0, max_bounces=2, threads=2)["screen"]
+            results["equal_pipelined"] &= bool(np.array_equal(prev.numpy().view(np.uint32), ref.view(np.uint32)))
     if rank == 0:
         results["splits"] = splits
         results["rendered"] = rendered
@@ -77,14 +97,15 @@ def _worker(rank, world, port, out_path):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_frame_assembly(tmp_path):
+@pytest.mark.parametrize("layout", ["tiles", "bands"])
+def test_two_rank_frame_assembly(tmp_path, layout):
     out = str(tmp_path / "res.pt")
-    mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, _free_port(), out, layout), nprocs=2, join=True, start_method="spawn")
     res = torch.load(out)
-    assert res["equal0"] and res["equal1"] and res["equal2"]
+    assert res["equal0"] and res["equal1"] and res["equal2"] and res["equal_pipelined"]
     s0, s1, s2 = res["splits"]
     n = s0[-1]
-    assert s0 == [0, n // 2, n] and s2 == s0          # uniform at start and after the camera move
+    assert s0[0] == 0 and s0[1] in (n // 2, (n + 1) // 2) and s0[2] == n and s2 == s0   # uniform at start and after the camera move
     assert s1 != s0 and s1[0] == 0 and s1[-1] == n    # rebalanced from the first frame's costs
 
 
@@ -110,5 +131,5 @@ def test_single_rank_path_without_process_group():
         cost.fill_(1)
 
     dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
-    frame = dr.render_frame()
-    assert np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32))
+    dr.render_frame()
+    assert np.array_equal(dr.finish().numpy().view(np.uint32), ref.view(np.uint32))
