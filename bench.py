@@ -194,17 +194,25 @@ def main():
         dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
                                    rebalance_every=1 if cameras else 16, stage_through_host=rehearsal)
-        ray_sums = []
         for _ in range(args.warmup):
             dr.render_frame()
         barrier()
+        first_timed = step_no[0]
         t0 = time.perf_counter()
         for _ in range(args.steps):
             dr.render_frame()
-            ray_sums.append(dr.rays_last_frame())  # device scalar, no sync
         dr.finish()
         barrier()
         elapsed = time.perf_counter() - t0
+        # rays of the timed frames, counted afterwards: the same seeds and cameras once more with per-tile ray
+        # counts switched on (the total does not depend on how the frame is split)
+        ray_sums = []
+        dr.rebalance_every = 0
+        step_no[0] = first_timed
+        for _ in range(args.steps):
+            dr.render_frame(want_cost=True)
+            ray_sums.append(dr.rays_last_frame())
+        dr.finish()
         local = torch.stack(ray_sums).double().sum().reshape(1)
         if rehearsal:
             local = local.cpu()

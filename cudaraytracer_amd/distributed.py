@@ -21,7 +21,8 @@ CPU ranks in tests:
     render_tiles(tile_ids, out, cost) -> None
         tile_ids : 1-D int array of the tiles this rank renders, in order
         out      : torch tensor [len(tile_ids), tile_h * tile_w, 4] float32 to fill
-        cost     : torch tensor [len(tile_ids)] float32 to fill (any positive cost measure)
+        cost     : torch tensor [len(tile_ids)] int32 to fill (any positive cost measure), or None when
+                   this frame's costs are not needed
 """
 import ctypes as C
 
@@ -175,12 +176,15 @@ class DistributedRenderer:
         """flat pixel range of bands [b0, b1) inside the frame (the last band may be cut by the frame's bottom edge)"""
         return b0 * self.tile_px, min(b1 * self.tile_px, self.width * self.height)
 
-    def render_frame(self):
+    def render_frame(self, want_cost=False):
         """One frame.  Returns the frame tensor on rank 0 (None elsewhere); with the bands layout its
-        exchange may still be in flight until finish() or until `depth` more frames were started."""
+        exchange may still be in flight until finish() or until `depth` more frames were started.
+        Per-tile costs are only measured on the frames whose costs are used: the one before a rebalance,
+        or when want_cost is set (render_tiles gets cost=None otherwise)."""
         p = self.plan
         b0, b1 = int(p.begin[self.rank]), int(p.begin[self.rank + 1])
-        cost = self.cost[b0:b1]
+        rebalance_now = bool(self.rebalance_every) and self.frames_since_rebalance + 1 >= self.rebalance_every
+        cost = self.cost[b0:b1] if (want_cost or rebalance_now) else None
         slot = self.frame_no % self.depth
         for w in self.pending[slot]:  # this buffer's previous exchange must be over before it is overwritten
             w.wait()
@@ -242,9 +246,9 @@ class DistributedRenderer:
 
         self.frame_no += 1
         self.last_cost = self.cost
-        self._rays_last = cost.sum() if b1 > b0 else torch.zeros((), dtype=torch.int64, device=self.device)
+        self._rays_last = cost.sum() if (cost is not None and b1 > b0) else None
         self.frames_since_rebalance += 1
-        if self.rebalance_every and self.frames_since_rebalance >= self.rebalance_every:
+        if rebalance_now:
             self.frames_since_rebalance = 0
             full = self.cost.to(torch.float32)
             if self.world > 1:
@@ -260,7 +264,10 @@ class DistributedRenderer:
         return self.frame if self.rank == 0 else None
 
     def rays_last_frame(self):
-        """Device scalar: rays this rank traced in the last frame (sum of its per-tile costs when the cost is a ray count)."""
+        """Device scalar: rays this rank traced in the last frame (sum of its per-tile costs when the cost is a
+        ray count).  Needs a frame rendered with costs (want_cost, or a frame that precedes a rebalance)."""
+        if self._rays_last is None:
+            return torch.zeros((), dtype=torch.int64, device=self.device)
         return self._rays_last
 
 
@@ -270,7 +277,7 @@ def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args):
     def fn(tile_ids, out, cost):
         args = frame_args() if callable(frame_args) else dict(frame_args)
         core.render(width, height, tile_ids=tile_ids, tile_w=tile_w, tile_h=tile_h, screen_dev=C.c_void_p(out.data_ptr()),
-                    tile_rays_dev=C.c_void_p(cost.data_ptr()), **args)
+                    tile_rays_dev=None if cost is None else C.c_void_p(cost.data_ptr()), **args)
     return fn
 
 

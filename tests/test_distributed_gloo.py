@@ -59,7 +59,8 @@ def _worker(rank, world, port, out_path, layout):
             c[k] = 1.0 + float((r["prim"][y0:y0 + h, x0:x0 + w] != 0xFFFFFFFF).sum())
         flat = out.view(-1, 4)
         flat.copy_(torch.from_numpy(buf.reshape(-1, 4)[:flat.shape[0]]))
-        cost.copy_(torch.from_numpy(c.astype(np.int32)))
+        if cost is not None:
+            cost.copy_(torch.from_numpy(c.astype(np.int32)))
         rendered.append(len(tile_ids))
 
     dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=tw, tile_h=TH)
@@ -128,7 +129,8 @@ def test_single_rank_path_without_process_group():
             w, h = min(TW, W - x0), min(TH, H - y0)
             buf[k, :h, :w] = ref[y0:y0 + h, x0:x0 + w]
         out.copy_(torch.from_numpy(buf.reshape(len(tile_ids), TH * TW, 4)))
-        cost.fill_(1)
+        if cost is not None:
+            cost.fill_(1)
 
     dr = D.DistributedRenderer(W, H, render_tiles, torch.device("cpu"), tile_w=TW, tile_h=TH)
     dr.render_frame()
