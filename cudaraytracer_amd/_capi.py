@@ -88,7 +88,8 @@ class Frame(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("seed", C.c_uint64), ("frames", C.c_uint64),
                 ("max_bounces", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("num_tiles", C.c_uint32), ("tile_ids", c_u32_p), ("pixel_values_dev", C.c_void_p),
-                ("collect_stats", C.c_uint32), ("tile_rays_dev", C.c_void_p), ("tile_cycles_dev", C.c_void_p)]
+                ("collect_stats", C.c_uint32), ("tile_rays_dev", C.c_void_p), ("tile_cycles_dev", C.c_void_p),
+                ("path_keys_dev", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -119,6 +120,7 @@ HIP_SYMBOLS = {
     "acr_hip_read_hit_t": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "acr_hip_read_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "acr_hip_framebuffer": (C.c_void_p, [C.c_void_p]),
+    "acr_hip_sort_pixel_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "acr_hip_scatter_tiles": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_void_p]),
 }

@@ -161,7 +161,7 @@ class HipCore:
 
     def render(self, width, height, seed=0, frames=0, max_bounces=1, collect_stats=False, screen_dev=None,
                primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None,
-               tile_rays_dev=None, tile_cycles_dev=None):
+               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None):
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
         f.collect_stats = 1 if collect_stats else 0
@@ -173,6 +173,7 @@ class HipCore:
         f.pixel_values_dev = pixel_values_dev
         f.tile_rays_dev = tile_rays_dev
         f.tile_cycles_dev = tile_cycles_dev
+        f.path_keys_dev = path_keys_dev
         self._check(self._lib.acr_hip_render(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render")
 
     def sync(self):
@@ -215,6 +216,10 @@ class HipCore:
                                                  prim.ctypes.data_as(_capi.c_u32_p), pos.ctypes.data_as(fp),
                                                  nrm.ctypes.data_as(fp)), "acr_hip_trace_rays")
         return dict(hit=hit, t=t, prim=prim, position=pos, normal=nrm)
+
+    def sort_pixel_map(self, path_keys_dev, pixel_values_dev, num_pixels):
+        """pixel_values <- pixel numbers stably sorted by traversal-path key (device pointers, asynchronous)"""
+        self._check(self._lib.acr_hip_sort_pixel_map(self._h, path_keys_dev, pixel_values_dev, num_pixels), "acr_hip_sort_pixel_map")
 
     def scatter_tiles(self, tiles_dev, tile_ids, tile_w, tile_h, width, height, frame_dev):
         ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)

@@ -5,6 +5,7 @@
 // There is no CPU fallback anywhere in this file: every compute entry point
 // either launches a HIP kernel or returns an error.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cfloat>
 #include <cmath>
@@ -63,6 +64,13 @@ struct acr_hip_ctx
 	uint32_t *redoList = nullptr;
 	size_t redoCap = 0;
 	uint32_t redoParity = 0;
+	uint32_t sceneDepthGiven = 0;  // MAX_DEPTH of the scene tree as uploaded (before unused levels were trimmed)
+	// scratch of acr_hip_sort_pixel_map
+	void *sortTemp = nullptr;
+	size_t sortTempBytes = 0;
+	uint64_t *sortKeysOut = nullptr;
+	int32_t *sortValuesIn = nullptr;
+	size_t sortCap = 0;
 	hipEvent_t evStart = nullptr, evStop = nullptr;
 	bool timed = false;
 	acr_stats stats{};
@@ -71,7 +79,8 @@ struct acr_hip_ctx
 
 namespace
 {
-	constexpr uint32_t kBlock = 256;
+	constexpr uint32_t kBlock = ACR_BLOCK;
+	constexpr uint32_t kBlockRows = kBlock / 16; // a workgroup covers 16 x kBlockRows pixels of a full frame
 	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
 	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
 	constexpr size_t kLdsBudget = 64 * 1024;
@@ -157,13 +166,18 @@ namespace
 		return true;
 	}
 
-	void putNode(uint4 &dst, float left, float right, uint32_t start, uint32_t end, uint8_t flags)
+	// Node i of a heap-ordered tree with `count` packed nodes.
+	void putNode(uint4 &dst, const float *left, const float *right, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t i,
+	             uint32_t count)
 	{
-		dst.x = fbits(left);
-		dst.y = fbits(right);
-		dst.z = start;
-		dst.w = (end & acr::dev::kNodeEndMask) | (uint32_t(flags & ACR_NODE_AXIS_MASK) << acr::dev::kNodeAxisShift) |
-		        ((flags & ACR_NODE_LEAF) ? acr::dev::kNodeLeafBit : 0u);
+		dst.x = fbits(left[i]);
+		dst.y = fbits(right[i]);
+		dst.z = start[i];
+		dst.w = (end[i] & acr::dev::kNodeEndMask) | (uint32_t(flags[i] & ACR_NODE_AXIS_MASK) << acr::dev::kNodeAxisShift) |
+		        ((flags[i] & ACR_NODE_LEAF) ? acr::dev::kNodeLeafBit : 0u);
+		// "left got more than right" (bih.h:269-270), used by the traversal-path key
+		const uint32_t l = 2 * i + 1, r = 2 * i + 2;
+		if (!(flags[i] & ACR_NODE_LEAF) && r < count && (end[l] - start[l]) > (end[r] - start[r])) dst.w |= acr::dev::kNodeLeftBiggerBit;
 	}
 
 	struct LaunchPlan
@@ -251,6 +265,9 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->counters);
 	(void)hipFree(ctx->redoCount);
 	(void)hipFree(ctx->redoList);
+	(void)hipFree(ctx->sortTemp);
+	(void)hipFree(ctx->sortKeysOut);
+	(void)hipFree(ctx->sortValuesIn);
 	(void)hipFree(ctx->renderTiles.dev);
 	(void)hipFree(ctx->scatterTiles.dev);
 	if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -366,7 +383,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 
 	std::vector<uint4> blob(h.total_slots ? h.total_slots : 1, make_uint4(0, 0, 0, 0));
 	for (uint32_t i = 0; i < snodeCount; i++)
-		putNode(blob[h.off_snodes + i], s->snode_left[i], s->snode_right[i], s->snode_start[i], s->snode_end[i], s->snode_flags[i]);
+		putNode(blob[h.off_snodes + i], s->snode_left, s->snode_right, s->snode_start, s->snode_end, s->snode_flags, i, snodeCount);
 	// margin of the conservative world boxes: three to four orders of magnitude above fp32 rounding at scene scale
 	double diag2 = 0;
 	for (int k = 0; k < 3; k++) diag2 += double(s->scene_max[k] - s->scene_min[k]) * double(s->scene_max[k] - s->scene_min[k]);
@@ -437,8 +454,8 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	for (uint32_t m = 0; m < s->num_meshes; m++) {
 		const uint32_t nb = s->mesh_node_begin[m], count = (1u << meshLevels[m]) - 1;
 		for (uint32_t i = 0; i < count; i++)
-			putNode(blob[h.off_mnodes + meshNodeAt[m] + i], s->mnode_left[nb + i], s->mnode_right[nb + i], s->mnode_start[nb + i],
-			        s->mnode_end[nb + i], s->mnode_flags[nb + i]);
+			putNode(blob[h.off_mnodes + meshNodeAt[m] + i], s->mnode_left + nb, s->mnode_right + nb, s->mnode_start + nb, s->mnode_end + nb,
+			        s->mnode_flags + nb, i, count);
 	}
 	for (uint32_t i = 0; i < s->num_triangles; i++) {
 		const float *a = s->tri_p0 + 3 * size_t(i), *b = s->tri_p1 + 3 * size_t(i), *c = s->tri_p2 + 3 * size_t(i);
@@ -468,6 +485,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	ACR_HIP_TRY(ctx, hipMemcpy(ctx->blob, blob.data(), ctx->blobBytes, hipMemcpyHostToDevice));
 	ctx->header = h;
 	ctx->intervalOk = intervalOk;
+	ctx->sceneDepthGiven = s->scene_depth;
 	ctx->haveScene = true;
 	return ACR_OK;
 }
@@ -530,9 +548,14 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		const uint64_t g = uint64_t(f->num_tiles) * (f->tile_w / 16) * (f->tile_h / 16);
 		if (g >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "too many tiles");
 		grid = uint32_t(g);
+		if (f->path_keys_dev) return fail(ctx, ACR_ERR_INVALID, "traversal-path keys need a full-frame launch");
 	} else {
 		if (f->tile_rays_dev || f->tile_cycles_dev) return fail(ctx, ACR_ERR_INVALID, "per-tile costs need a tile list");
-		grid = ((f->width + 15) / 16) * ((f->height + 15) / 16);
+		// A traversal takes 2 * MAX_SIZE bits of the Path's length (bih.h:293-297): from MAX_DEPTH 6 on that is more
+		// than the 64 bits of the key, so only the primary ray's traversal reaches it, which is what the kernels record.
+		if (f->path_keys_dev && ctx->sceneDepthGiven < 6)
+			return fail(ctx, ACR_ERR_UNSUPPORTED, "traversal-path keys need a scene BIH of MAX_DEPTH >= 6 (got %u)", ctx->sceneDepthGiven);
+		grid = ((f->width + 15) / 16) * ((f->height + kBlockRows - 1) / kBlockRows);
 	}
 
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -561,6 +584,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	p.num_tiles = f->num_tiles;
 	p.tile_ids = ctx->renderTiles.dev;
 	p.pixel_values = f->pixel_values_dev;
+	p.path_keys = f->path_keys_dev;
 	p.screen = ownBuffers ? ctx->screen : static_cast<float4 *>(screen_dev);
 	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
 	p.hit_t = hit_t_dev ? hit_t_dev : (ownBuffers ? ctx->hitT : nullptr);
@@ -578,6 +602,9 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		if (ctx->redoCap < slots) {
 			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 			(void)hipFree(ctx->redoList);
+	(void)hipFree(ctx->sortTemp);
+	(void)hipFree(ctx->sortKeysOut);
+	(void)hipFree(ctx->sortValuesIn);
 			ctx->redoList = nullptr;
 			ctx->redoCap = 0;
 			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->redoList), slots * sizeof(uint32_t)));
@@ -710,6 +737,37 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 }
 
 void *acr_hip_framebuffer(acr_hip_ctx *ctx) { return ctx ? ctx->screen : nullptr; }
+
+int acr_hip_sort_pixel_map(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *pixel_values_dev, uint32_t num_pixels)
+{
+	if (!ctx || !path_keys_dev || !pixel_values_dev) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (num_pixels == 0) return ACR_OK;
+	if (num_pixels >= (1u << 31)) return fail(ctx, ACR_ERR_INVALID, "too many pixels");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	size_t need = 0;
+	ACR_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, need, path_keys_dev, ctx->sortKeysOut, ctx->sortValuesIn, pixel_values_dev, int(num_pixels),
+	                                                    0, 64, ctx->stream));
+	if (ctx->sortCap < num_pixels || ctx->sortTempBytes < need) {
+		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		(void)hipFree(ctx->sortTemp); ctx->sortTemp = nullptr;
+		(void)hipFree(ctx->sortKeysOut); ctx->sortKeysOut = nullptr;
+		(void)hipFree(ctx->sortValuesIn); ctx->sortValuesIn = nullptr;
+		ctx->sortCap = 0;
+		ctx->sortTempBytes = 0;
+		ACR_HIP_TRY(ctx, hipMalloc(&ctx->sortTemp, need));
+		ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sortKeysOut), size_t(num_pixels) * sizeof(uint64_t)));
+		ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sortValuesIn), size_t(num_pixels) * sizeof(int32_t)));
+		ctx->sortCap = num_pixels;
+		ctx->sortTempBytes = need;
+	}
+	// thrust::sequence(pixelValues) (renderer.cu:137), then stable_sort_by_key(pixelKeys, pixelValues) (renderer.cu:460):
+	// an LSD radix sort is stable
+	ACR_HIP_TRY(ctx, acr_dev_launch_iota(ctx->sortValuesIn, num_pixels, ctx->stream));
+	size_t bytes = ctx->sortTempBytes;
+	ACR_HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sortTemp, bytes, path_keys_dev, ctx->sortKeysOut, ctx->sortValuesIn, pixel_values_dev,
+	                                                    int(num_pixels), 0, 64, ctx->stream));
+	return ACR_OK;
+}
 
 int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_t *tile_ids, uint32_t num_tiles,
                           uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, void *frame_dev)

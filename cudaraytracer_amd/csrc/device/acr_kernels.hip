@@ -43,7 +43,7 @@ namespace acr
 namespace dev
 {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = ACR_BLOCK;
 // resident waves per SIMD the render kernel is compiled for (sets its VGPR budget: 512 / waves)
 #ifndef ACR_RENDER_WAVES
 #define ACR_RENDER_WAVES 4
@@ -127,6 +127,23 @@ __device__ __forceinline__ bool slabTest(const vec3 &nearT, const vec3 &farT, fl
 	return tmin < tcur && tmax > epsilon();
 }
 
+// Path of renderer.cu:341 (bih.h:13-27) as designed: two bits per internal node visited, appended from the
+// most significant end; what no longer fits is dropped.
+struct PathRec
+{
+	uint64_t path;
+	uint32_t length;
+	// bih.h:269-274: 00 neither child hit, 11 both, 10 the child with more items, 01 the other one
+	__device__ __forceinline__ void append(bool hitL, bool hitR, bool lBigger)
+	{
+		length += 2;
+		if (length <= 64) {
+			const uint64_t flag = lBigger ? ((uint64_t(hitL) << 1) | uint64_t(hitR)) : ((uint64_t(hitR) << 1) | uint64_t(hitL));
+			path |= flag << (64 - length);
+		}
+	}
+};
+
 __device__ __forceinline__ vec3 withComp(const vec3 &v, uint32_t axis, float f)
 {
 	return vec3(axis == 0 ? f : v.x, axis == 1 ? f : v.y, axis == 2 ? f : v.z);
@@ -137,9 +154,9 @@ __device__ __forceinline__ vec3 withComp(const vec3 &v, uint32_t axis, float f)
 // (used by shadow rays only); tcur() is the current info.t the slab tests
 // compare against (bih.h:247-248 pass `info`).  `undo` points at this lane's
 // column: undo[level * kBlock].
-template <class LoadNode, class Leaf, class TCur>
+template <bool KEYS = false, class LoadNode, class Leaf, class TCur>
 __device__ __forceinline__ void bihTraverse(LoadNode loadNode, uint32_t maxDepth, const SlabArgs &sa, const SlabBox &root,
-                                            float *undo, Leaf leaf, TCur tcur)
+                                            float *undo, Leaf leaf, TCur tcur, PathRec *path = nullptr)
 {
 	uint32_t idx = 0, level = 0, pending = 0;
 	uint64_t axes = 0; // 2 bits per level: split axis of the path node at that level
@@ -163,6 +180,7 @@ __device__ __forceinline__ void bihTraverse(LoadNode loadNode, uint32_t maxDepth
 			const float tc = tcur();
 			const bool hitL = slabTest(lNear, lFar, tc);
 			const bool hitR = slabTest(rNear, rFar, tc);
+			if constexpr (KEYS) path->append(hitL, hitR, (n.w & kNodeLeftBiggerBit) != 0);
 			if (hitL || hitR) {
 				// left first; a right child that also hit waits (bih.h:253-264)
 				if (hitL && hitR) pending |= 1u << level;
@@ -261,8 +279,9 @@ __device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) 
 // Loop shape: an inner loop that only descends (a lane leaves it at a leaf, or when its traversal has
 // nothing left), then the leaf's items, then the pop.  Lanes of a wave therefore do their node steps
 // together and their item tests together instead of interleaving the two.
-template <class LoadNode, class Leaf, class TCur>
-__device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, float2 *stack, Leaf leaf, TCur tcur)
+template <bool KEYS = false, class LoadNode, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, float2 *stack, Leaf leaf, TCur tcur,
+                                                PathRec *path = nullptr)
 {
 	uint32_t idx = 0, level = 0, pending = 0;
 	float tminB = box.tmin, tmaxB = box.tmax;
@@ -286,6 +305,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 			const bool hitFarSide = intervalHit(farSideMin, tmaxB, tc);
 			const bool hitL = sg ? hitFarSide : hitNearSide;
 			const bool hitR = sg ? hitNearSide : hitFarSide;
+			if constexpr (KEYS) path->append(hitL, hitR, (n.w & kNodeLeftBiggerBit) != 0);
 			if (hitL || hitR) {
 				// left first; a right child that also hit waits (bih.h:253-264)
 				const bool takeFarSide = hitL ? sg : !sg;
@@ -535,9 +555,9 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 // objects can be skipped without changing it.  (The boolean `intersected` the
 // reference also tests is implied: info.t can only drop below t through a
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
-template <bool SHADOW, bool FAST, class Mem>
+template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               float *undoScene, float *undoMesh, bool &bail)
+                                               float *undoScene, float *undoMesh, bool &bail, PathRec *path = nullptr)
 {
 	SlabArgs sa;
 	sa.init(r);
@@ -568,11 +588,11 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	};
 	auto tcur = [&]() { return info.t; };
 	if constexpr (FAST) {
-		bihTraverseFast(loadNode, sa, boxInterval(sa, smin, smax), reinterpret_cast<float2 *>(undoScene), leaf, tcur);
+		bihTraverseFast<KEYS>(loadNode, sa, boxInterval(sa, smin, smax), reinterpret_cast<float2 *>(undoScene), leaf, tcur, path);
 	} else {
 		SlabBox root;
 		root.init(sa, smin, smax);
-		bihTraverse(loadNode, sc.scene_depth, sa, root, undoScene, leaf, tcur);
+		bihTraverse<KEYS>(loadNode, sc.scene_depth, sa, root, undoScene, leaf, tcur, path);
 	}
 	return SHADOW ? occluded : intersected;
 }
@@ -707,7 +727,8 @@ struct SlotResult
 // scatterTrace (renderer.cu:326-388) for one pixel slot, with rayColor<N> (renderer.cu:232-324) unrolled into a loop.
 // (vblock, vtid) name the slot: workgroup vblock of the frame's launch grid, work-item vtid in it.  The LDS
 // columns belong to the executing work-item (threadIdx.x), which need not be vtid.
-template <bool FAST, class Mem>
+// KEYS: also records the pixel's traversal-path key (the reference's per-pixel Path, renderer.cu:341,372,380,386).
+template <bool FAST, bool KEYS, class Mem>
 __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
 	const SceneHeader &sc = p.scene;
@@ -737,7 +758,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
 	} else {
 		oldx = (vblock % p.blocks_x) * 16u + lx;
-		oldy = (vblock / p.blocks_x) * 16u + ly;
+		oldy = (vblock / p.blocks_x) * uint32_t(kBlock / 16) + ly;
 		outSlot = 0;
 	}
 
@@ -776,6 +797,9 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 	vec4 tail(0, 0, 0, 1);
 	uint32_t level = 0;
 	bool bail = false;
+	PathRec pathRec;
+	pathRec.path = 0;
+	pathRec.length = 0;
 	// stored early so that they need no registers later; a pixel that bails is written again by the list pass
 	if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
 	if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
@@ -789,7 +813,15 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
 		if (level > 0) cnt.bounce++;
-		const bool hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+		bool hit;
+		if constexpr (KEYS) {
+			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
+			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, &pathRec);
+			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+		} else {
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+		}
 		if (FAST && bail) break;
 		if (!hit)
 			break; // renderer.cu:315
@@ -877,6 +909,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		const vec4 cl(cstack[(3 * level + 0) * kBlock], cstack[(3 * level + 1) * kBlock], cstack[(3 * level + 2) * kBlock], 1.0f);
 		contribution = cl + contribution;
 	}
+	if constexpr (KEYS) p.path_keys[index] = pathRec.path; // keyed by pixel, so that keys and pixels stay together when sorted
 
 	// average (renderer.cu:375-387)
 	float4 *px = p.screen + outSlot;
@@ -918,7 +951,7 @@ __device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotRe
 
 // One work-item per pixel slot of the frame (or of the listed tiles).
 // FAST: interval traversal; pixels it cannot serve are appended to p.redo_list for renderListKernel.
-template <bool SMALL_LDS, bool LARGE_LDS, bool FAST>
+template <bool SMALL_LDS, bool LARGE_LDS, bool FAST, bool KEYS>
 __global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES) renderKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
@@ -929,7 +962,7 @@ __global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES) renderKernel(const R
 
 	const bool tiled = p.num_tiles != 0;
 	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
-	const SlotResult res = renderSlot<FAST>(p, mem, blockIdx.x, threadIdx.x);
+	const SlotResult res = renderSlot<FAST, KEYS>(p, mem, blockIdx.x, threadIdx.x);
 	if constexpr (FAST) {
 		if (res.bail) {
 			const uint32_t at = atomicAdd(p.redo_count, 1u);
@@ -943,7 +976,7 @@ __global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES) renderKernel(const R
 
 // Renders the pixel slots listed by a FAST launch with the six-plane traversal: a fixed small grid that
 // strides over the list (usually empty).  Also zeroes the counter the NEXT frame's FAST launch appends with.
-template <bool SMALL_LDS, bool LARGE_LDS>
+template <bool SMALL_LDS, bool LARGE_LDS, bool KEYS>
 __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 {
 	const uint32_t count = *p.redo_count;
@@ -965,7 +998,7 @@ __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 		if (k < count) {
 			const uint32_t slot = p.redo_list[k];
 			vblock = slot / kBlock;
-			res = renderSlot<false>(p, mem, vblock, slot % kBlock);
+			res = renderSlot<false, KEYS>(p, mem, vblock, slot % kBlock);
 		}
 		// lanes of one wave may belong to different tiles and blocks here: count per lane
 		if (res.active) {
@@ -1060,20 +1093,39 @@ namespace
 } // namespace
 
 // fast != 0: interval traversal for the whole grid, then the six-plane list pass over whatever it handed back
-// (p->redo_* must be set).  fast == 0: six-plane traversal for the whole grid.
-extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+// (p->redo_* must be set).  fast == 0: six-plane traversal for the whole grid.  p->path_keys selects the
+// variants that also record the per-pixel traversal-path key.
+template <bool KEYS>
+static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
 {
 	using namespace acr::dev;
 	typedef void (*K)(const RenderParams);
 	if (!fast) {
-		K k = ldsMode == 2 ? renderKernel<true, true, false> : (ldsMode == 1 ? renderKernel<true, false, false> : renderKernel<false, false, false>);
+		K k = ldsMode == 2 ? renderKernel<true, true, false, KEYS> : (ldsMode == 1 ? renderKernel<true, false, false, KEYS> : renderKernel<false, false, false, KEYS>);
 		return launchWithLds(k, *p, grid, ldsBytes, stream);
 	}
-	K k = ldsMode == 2 ? renderKernel<true, true, true> : (ldsMode == 1 ? renderKernel<true, false, true> : renderKernel<false, false, true>);
+	K k = ldsMode == 2 ? renderKernel<true, true, true, KEYS> : (ldsMode == 1 ? renderKernel<true, false, true, KEYS> : renderKernel<false, false, true, KEYS>);
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
-	K kl = ldsMode == 2 ? renderListKernel<true, true> : (ldsMode == 1 ? renderListKernel<true, false> : renderListKernel<false, false>);
+	K kl = ldsMode == 2 ? renderListKernel<true, true, KEYS> : (ldsMode == 1 ? renderListKernel<true, false, KEYS> : renderListKernel<false, false, KEYS>);
 	return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream);
+}
+
+extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
+{
+	return p->path_keys ? launchRender<true>(p, ldsMode, fast, grid, ldsBytes, stream) : launchRender<false>(p, ldsMode, fast, grid, ldsBytes, stream);
+}
+
+// values[i] = i (thrust::sequence at renderer.cu:137)
+__global__ void __launch_bounds__(256) iotaKernel(int32_t *values, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) values[i] = int32_t(i);
+}
+extern "C" hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(iotaKernel, dim3((n + 255) / 256), dim3(256), 0, stream, values, n);
+	return hipGetLastError();
 }
 
 extern "C" hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)

@@ -3,7 +3,7 @@
 // acr_hip_upload_scene, read by the kernels in acr_kernels.hip.
 //
 // Record formats (one uint4 = one slot; f = float bits, u = uint32):
-//   BIH node   1 slot : { f left, f right, u start, u end | axis<<28 | leaf<<30 }   (bih.h:92-98)
+//   BIH node   1 slot : { f left, f right, u start, u end | axis<<28 | leaf<<30 | leftBigger<<31 }   (bih.h:92-98)
 //   object    16 slots: [0]     world box min - margin (3 f), u flags (kObj* below)
 //                       [1]     world box max + margin (3 f), 0
 //                       [2..5]  globalInverseTransform columns
@@ -33,6 +33,7 @@ namespace acr
 namespace dev
 {
 	constexpr uint32_t kNodeLeafBit = 1u << 30;
+	constexpr uint32_t kNodeLeftBiggerBit = 1u << 31; // internal node: the left child holds more items than the right (bih.h:269-270)
 	constexpr uint32_t kNodeAxisShift = 28;
 	constexpr uint32_t kNodeEndMask = (1u << 28) - 1;
 

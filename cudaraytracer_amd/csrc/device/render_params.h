@@ -9,6 +9,11 @@
 
 #include "device_scene.h"
 
+// work-items per workgroup of the render kernels; a workgroup covers 16 x (ACR_BLOCK / 16) pixels
+#ifndef ACR_BLOCK
+#define ACR_BLOCK 256
+#endif
+
 namespace acr
 {
 namespace dev
@@ -42,6 +47,7 @@ namespace dev
 		uint32_t *redo_count;       // device: entries in redo_list (this frame)
 		uint32_t *redo_count_next;  // device: the counter the next frame will use; the list pass zeroes it
 		uint32_t *redo_list;        // device [grid * 256]
+		uint64_t *path_keys;        // device [width * height] or null: per-pixel traversal-path key (full-frame launches)
 	};
 
 	// workgroups of the list pass
@@ -64,6 +70,7 @@ namespace dev
 
 extern "C" {
 hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
+hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream);
 hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
                                         uint32_t width, uint32_t height, void *frame, hipStream_t stream);

@@ -154,6 +154,12 @@ typedef struct acr_frame {
 	 * from run to run).  Either may be NULL.  Tile mode only. */
 	uint32_t *tile_rays_dev;
 	uint32_t *tile_cycles_dev;
+	/* Optional per-pixel traversal-path key: device uint64[width*height] or NULL.  Entry i receives the Path of
+	 * pixel i as the reference designed it (bih.h:13-27,268-274: two bits per internal node the primary ray visits
+	 * in the tree over objects, most significant first: 00 neither child hit, 11 both, 10 the child with more
+	 * items, 01 the other; renderer.cu:341,372).  Full-frame launches on scenes whose object tree was built with
+	 * MAX_DEPTH >= 6.  Input of acr_hip_sort_pixel_map. */
+	uint64_t *path_keys_dev;
 } acr_frame;
 
 typedef struct acr_stats {
@@ -226,6 +232,14 @@ int acr_hip_read_hit_t(acr_hip_ctx *ctx, float *t, size_t count);
 int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats);
 /* device address of the context-owned framebuffer (NULL before acr_hip_resize) */
 void *acr_hip_framebuffer(acr_hip_ctx *ctx);
+
+/* The reference's adaptive assignment step (renderer.cu:131-137,457-461; disabled at its v0): fills
+ * pixel_values_dev[0..num_pixels) with the pixel numbers 0..num_pixels-1 stably sorted by their traversal-path
+ * key (thrust::sequence + thrust::stable_sort_by_key), so that neighbouring work-items of later frames
+ * (frames > 0, acr_frame::pixel_values_dev) render pixels whose primary rays traverse alike.  Keys are indexed
+ * by pixel, so a pixel's history follows it through the sort.  Device pointers; asynchronous on the
+ * context's stream. */
+int acr_hip_sort_pixel_map(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *pixel_values_dev, uint32_t num_pixels);
 
 /* Copies compact tiles (as written by a tiled acr_hip_render) into a full
  * [height][width] float4 frame on the same device: the last step after the

@@ -405,7 +405,19 @@ typedef struct { v3 invD; int sign[3]; } bbargs_t;          /* geometry.h:31-35 
 
 typedef struct {
 	orc_counters c;
+	/* Path of renderer.cu:341 (bih.h:13-27), one per pixel, threaded through every Scene::intersect of the pixel */
+	uint64_t path, path_length;
 } stats_t;
+
+/* Path::append as designed (bih.h:21-26; the body is commented out in the reference and tests `length` against
+ * sizeof(path) = 8 where the 64 bits of `path` are meant): bits are appended from the most significant end,
+ * whatever no longer fits is dropped. */
+static void path_append(stats_t *st, uint64_t flag, uint64_t size)
+{
+	st->path_length += size;
+	if (st->path_length <= 64 && flag)
+		st->path |= flag << (64 - st->path_length);
+}
 
 /* geometry.h:44-76 */
 static int bbox_intersect_args(const bbox_t *bb, const ray_t *r, float info_t, const bbargs_t *args, stats_t *st)
@@ -603,11 +615,13 @@ static int bih_sift(bih_t *bih, size_t index, const bbox_t *bbp, bih_items_t *h,
 
 typedef int (*item_intersect_fn)(const void *items, uint32_t i, const ray_t *r, hitinfo_t *info, const void *data, stats_t *st);
 
-/* bih.h:209-299 (Path bookkeeping omitted: every Path body is commented out at bih.h:21-26) */
+/* bih.h:209-299.  record_path: the traversal appends to the pixel's Path (bih.h:268-274,293-297); only the
+ * tree over objects is called with a Path in the reference (scene.cu:206), the mesh trees are not. */
 static int bih_tree_intersect(const bih_t *bih, const void *objs, item_intersect_fn item_intersect,
-                              const ray_t *r, hitinfo_t *info, const void *data, stats_t *st)
+                              const ray_t *r, hitinfo_t *info, const void *data, stats_t *st, int record_path)
 {
 	int intersected = 0;
+	uint64_t bitsAppended = 0;
 	int treeIdx[ORC_MAX_STACK];
 	bbox_t treeBB[ORC_MAX_STACK];
 	int depth = 0;
@@ -653,6 +667,14 @@ static int bih_tree_intersect(const bih_t *bih, const void *objs, item_intersect
 				depth++;
 			}
 			depth--;
+
+			if (record_path) {
+				/* left got more than right (bih.h:269-270) */
+				const int lBigger = (tree[lIdx].end - tree[lIdx].start) > (tree[rIdx].end - tree[rIdx].start);
+				/* 00 neither hit, 11 both, 10 the bigger child, 01 the smaller one (bih.h:272-274) */
+				path_append(st, ((uint64_t)hitL << lBigger) | ((uint64_t)hitR << !lBigger), 2);
+				bitsAppended += 2;
+			}
 		}
 
 		if (depth >= 0) {
@@ -666,6 +688,10 @@ static int bih_tree_intersect(const bih_t *bih, const void *objs, item_intersect
 				depth--;
 			}
 		}
+	}
+	if (record_path) { /* bih.h:293-297: every traversal takes 2 * MAX_SIZE bits of the Path's length */
+		const uint64_t total = 2ull * bih->max_size;
+		if (total > bitsAppended) path_append(st, 0, total - bitsAppended);
 	}
 	return intersected;
 }
@@ -758,7 +784,7 @@ static int mesh_intersect(const mesh_t *m, const ray_t *r, hitinfo_t *info, stat
 	fc.prim_base = m->prim_base;
 	if (bbox_intersect_args(&m->boundingBox, r, info->t, &args, st)
 	    && (st->c.mesh_box_hits++, 1)
-	    && bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st)) {
+	    && bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st, 0)) {
 		info->materialIndex = m->materialIndex;
 		return 1;
 	}
@@ -905,7 +931,7 @@ static v3 object_centroid_cb(const void *item, const void *data) { (void)data; r
 /* scene.cu:204-207 */
 static int scene_intersect(const orc_scene *s, const ray_t *r, hitinfo_t *info, stats_t *st)
 {
-	return bih_tree_intersect(&s->objects, s->object_items, object_item_intersect, r, info, s->meshes, st);
+	return bih_tree_intersect(&s->objects, s->object_items, object_item_intersect, r, info, s->meshes, st, 1);
 }
 
 /* scene.cu:209-231 */
@@ -1289,6 +1315,8 @@ static void scatter_trace_pixel(const orc_scene *scene, const orc_camera *cam, c
 
 	rec.hit = 0;
 	st->c.rays_primary++;
+	st->path = 0;          /* Path path; (renderer.cu:341) */
+	st->path_length = 0;
 	contribution = ray_color(f->max_bounces, &r, V3(1, 1, 1), scene, &state, st, &rec);
 	if (rec.hit) st->c.primary_hits++;
 
@@ -1302,6 +1330,7 @@ static void scatter_trace_pixel(const orc_scene *scene, const orc_camera *cam, c
 
 	if (aov) {
 		size_t k = (size_t)index;
+		if (aov->path_key) aov->path_key[k] = st->path;
 		if (aov->prim) aov->prim[k] = rec.hit ? rec.info.prim : 0xFFFFFFFFu;
 		if (aov->t) aov->t[k] = rec.hit ? rec.info.t : FLT_MAX;
 		if (aov->material) aov->material[k] = rec.hit ? rec.info.materialIndex : 0xFFFFFFFFu;

@@ -121,6 +121,7 @@ typedef struct orc_aov {
 	uint32_t *material;  /* materialIndex, 0xFFFFFFFF on miss */
 	float *position;     /* 3 per pixel */
 	float *normal;       /* 3 per pixel */
+	uint64_t *path_key;  /* the pixel's Path::path after rayColor (renderer.cu:341,372; bih.h:13-27,268-274) */
 } orc_aov;
 
 orc_scene *orc_scene_create(const orc_import_scene *imp, uint32_t scene_bih_depth, uint32_t mesh_bih_depth);

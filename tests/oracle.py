@@ -38,7 +38,8 @@ class OrcFrame(C.Structure):
 
 
 class OrcAov(C.Structure):
-    _fields_ = [("prim", c_u32_p), ("t", c_float_p), ("material", c_u32_p), ("position", c_float_p), ("normal", c_float_p)]
+    _fields_ = [("prim", c_u32_p), ("t", c_float_p), ("material", c_u32_p), ("position", c_float_p), ("normal", c_float_p),
+                ("path_key", C.POINTER(C.c_uint64))]
 
 
 _lib = None
@@ -188,9 +189,9 @@ class OracleScene:
         if aov:
             res.update(prim=np.full(n, 0xFFFFFFFF, np.uint32), t=np.full(n, np.finfo(np.float32).max, np.float32),
                        material=np.full(n, 0xFFFFFFFF, np.uint32), position=np.zeros((n, 3), np.float32),
-                       normal=np.zeros((n, 3), np.float32))
+                       normal=np.zeros((n, 3), np.float32), path_key=np.zeros(n, np.uint64))
             a = OrcAov(res["prim"].ctypes.data_as(c_u32_p), _fp(res["t"]), res["material"].ctypes.data_as(c_u32_p),
-                       _fp(res["position"]), _fp(res["normal"]))
+                       _fp(res["position"]), _fp(res["normal"]), res["path_key"].ctypes.data_as(C.POINTER(C.c_uint64)))
         cnt = OrcCounters()
         cam = camera if camera is not None else self.camera
         pm = None if pixel_map is None else pixel_map.ctypes.data_as(C.POINTER(C.c_int32))
@@ -201,6 +202,7 @@ class OracleScene:
         if aov:
             res["prim"] = res["prim"].reshape(height, width)
             res["t"] = res["t"].reshape(height, width)
+            res["path_key"] = res["path_key"].reshape(height, width)
         return res
 
     def trace_rays(self, origins, dirs, tmax=None):

@@ -431,3 +431,46 @@ def test_soup_10m_triangles_full_size(core, acr, orc):
         x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
         ww, hh = min(tw, w - x0), min(th, h - y0)
         assert np.array_equal(t[n, :hh, :ww].view(np.uint32), img[y0:y0 + hh, x0:x0 + ww].view(np.uint32))
+
+
+def test_traversal_path_keys_and_sorted_pixel_map(core, built):
+    """The reference's adaptive assignment, as designed (bih.h:13-27,268-274; renderer.cu:131-137,343-355,457-461):
+    frame 0 records a 64-bit traversal-path key per pixel, the pixel numbers are stably sorted by key, later
+    frames run through the sorted table.  Keys, table and the frames rendered through it all equal the oracle's."""
+    import torch
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 320, 180
+    n = w * h
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    table = torch.zeros(n, dtype=torch.int32, device="cuda")
+    core.resize(w, h)
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for six_plane in (True, False):
+            core.set_traversal(six_plane_only=six_plane)
+            keys.zero_()
+            core.render(w, h, seed=40, frames=0, max_bounces=3, path_keys_dev=C.c_void_p(keys.data_ptr()),
+                        pixel_values_dev=C.c_void_p(table.data_ptr()))
+            core.sync()
+            ref0 = b.oracle.render(w, h, seed=40, frames=0, max_bounces=3)
+            k = keys.cpu().numpy().view(np.uint64)
+            assert np.array_equal(k, ref0["path_key"].reshape(-1))
+            assert np.array_equal(core.read_framebuffer().view(np.uint32), ref0["screen"].view(np.uint32))
+            assert np.array_equal(table.cpu().numpy(), np.arange(n, dtype=np.int32))  # frames == 0 resets the table (renderer.cu:344-348)
+        assert len(np.unique(k)) > 8  # the keys do tell pixels apart
+        core.sort_pixel_map(C.c_void_p(keys.data_ptr()), C.c_void_p(table.data_ptr()), n)
+        core.sync()
+        perm = table.cpu().numpy()
+        assert np.array_equal(perm, np.argsort(k, kind="stable").astype(np.int32))
+        # frames 1..3 through the sorted table
+        screen = ref0["screen"]
+        for f in (1, 2, 3):
+            core.render(w, h, seed=40 + f, frames=f, max_bounces=3, pixel_values_dev=C.c_void_p(table.data_ptr()))
+            screen = b.oracle.render(w, h, seed=40 + f, frames=f, max_bounces=3, screen=screen, pixel_map=perm)["screen"]
+        core.sync()
+        assert np.array_equal(core.read_framebuffer().view(np.uint32), screen.view(np.uint32))
+        assert np.array_equal(table.cpu().numpy(), perm)  # frames > 0 leave the table alone
+    finally:
+        core.set_traversal(six_plane_only=False)
+        core.use_own_stream()

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--extent", type=float, default=10.0)
     ap.add_argument("--aov", action="store_true", help="also write primitive ids and hit distances")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--nolights", action="store_true", help="drop the scene's lights (primary rays only)")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
 
@@ -52,6 +53,8 @@ def main():
         scene = acr.Scene(import_view=view, mesh_bih_depth=args.depth)
     else:
         data = acr.ImportData.load(os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".json"))
+        if args.nolights:
+            data.lights = []
         view, keep = data.pack()
         scene = acr.Scene(import_view=view)
     t_build = time.perf_counter() - t0
