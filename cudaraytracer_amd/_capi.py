@@ -120,6 +120,8 @@ HIP_SYMBOLS = {
     "acr_hip_read_hit_t": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "acr_hip_read_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "acr_hip_framebuffer": (C.c_void_p, [C.c_void_p]),
+    "acr_hip_pixel_map": (C.c_void_p, [C.c_void_p]),
+    "acr_hip_path_keys": (C.c_void_p, [C.c_void_p]),
     "acr_hip_sort_pixel_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "acr_hip_scatter_tiles": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_void_p]),
@@ -148,6 +150,7 @@ HOST_SYMBOLS = {
     "acr_host_renderer_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_host_renderer_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_host_renderer_configure": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32]),
+    "acr_host_renderer_set_adaptive": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "acr_host_renderer_render": (C.c_int, [C.c_void_p]),
     "acr_host_renderer_frames_no_move": (C.c_uint64, [C.c_void_p]),
     "acr_host_renderer_read": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_u32_p, c_float_p]),

@@ -256,6 +256,11 @@ class Renderer:
     def configure(self, max_bounces=5, fixed_seed=-1, collect_stats=False):
         self._check(self._lib.acr_host_renderer_configure(self._h, max_bounces, fixed_seed, 1 if collect_stats else 0), "configure")
 
+    def set_adaptive(self, on, every=60):
+        """The reference's adaptive assignment (off by default, as at the reference's v0): re-sort the pixel
+        table by traversal-path key every `every` frames without a camera move."""
+        self._check(self._lib.acr_host_renderer_set_adaptive(self._h, 1 if on else 0, every), "setAdaptiveAssignment")
+
     def load_scene(self, scene):
         self._check(self._lib.acr_host_renderer_load_scene(self._h, scene.handle), "loadScene")
 

@@ -46,6 +46,7 @@ struct acr_hip_ctx
 	uint32_t *primid = nullptr;
 	float *hitT = nullptr;
 	int32_t *pixelValues = nullptr;
+	uint64_t *pathKeys = nullptr;
 
 	// per-launch scratch
 	unsigned long long *counters = nullptr; // device [kCounterSlots][4]
@@ -262,6 +263,7 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->primid);
 	(void)hipFree(ctx->hitT);
 	(void)hipFree(ctx->pixelValues);
+	(void)hipFree(ctx->pathKeys);
 	(void)hipFree(ctx->counters);
 	(void)hipFree(ctx->redoCount);
 	(void)hipFree(ctx->redoList);
@@ -514,12 +516,17 @@ int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height)
 	(void)hipFree(ctx->primid); ctx->primid = nullptr;
 	(void)hipFree(ctx->hitT); ctx->hitT = nullptr;
 	(void)hipFree(ctx->pixelValues); ctx->pixelValues = nullptr;
+	(void)hipFree(ctx->pathKeys); ctx->pathKeys = nullptr;
 	ctx->width = ctx->height = 0;
 	const size_t n = size_t(width) * height;
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->screen), n * sizeof(float4)));
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->primid), n * sizeof(uint32_t)));
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->hitT), n * sizeof(float)));
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pixelValues), n * sizeof(int32_t)));
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pathKeys), n * sizeof(uint64_t)));
+	ACR_HIP_TRY(ctx, acr_dev_launch_iota(ctx->pixelValues, uint32_t(n), ctx->stream));
+	ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->pathKeys, 0, n * sizeof(uint64_t), ctx->stream));
+	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ACR_HIP_TRY(ctx, hipMemset(ctx->screen, 0, n * sizeof(float4)));
 	ctx->width = width;
 	ctx->height = height;
@@ -737,6 +744,8 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 }
 
 void *acr_hip_framebuffer(acr_hip_ctx *ctx) { return ctx ? ctx->screen : nullptr; }
+int32_t *acr_hip_pixel_map(acr_hip_ctx *ctx) { return ctx ? ctx->pixelValues : nullptr; }
+uint64_t *acr_hip_path_keys(acr_hip_ctx *ctx) { return ctx ? ctx->pathKeys : nullptr; }
 
 int acr_hip_sort_pixel_map(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *pixel_values_dev, uint32_t num_pixels)
 {

@@ -280,6 +280,11 @@ int acr_host_renderer_configure(acr_host_renderer *r, uint32_t max_bounces, int6
 	});
 }
 
+int acr_host_renderer_set_adaptive(acr_host_renderer *r, uint32_t on, uint32_t every)
+{
+	return guarded(r, [&] { r->renderer->setAdaptiveAssignment(on != 0, every); });
+}
+
 int acr_host_renderer_render(acr_host_renderer *r)
 {
 	return guarded(r, [&] { r->renderer->render(); });

@@ -89,7 +89,14 @@ namespace acr
 		f.frames = framesNoMove;
 		f.max_bounces = maxBounces;
 		f.collect_stats = collectStats ? 1u : 0u;
+		const bool resort = adaptive && (framesNoMove + 1) % pixelMapFrameMod == 0; // renderer.cu:457
+		if (adaptive) {
+			f.pixel_values_dev = acr_hip_pixel_map(ctx);                // renderer.cu:343-355
+			if (resort) f.path_keys_dev = acr_hip_path_keys(ctx);       // renderer.cu:380,386
+		}
 		check(acr_hip_render(ctx, &f, nullptr, nullptr, nullptr), "acr_hip_render");
+		if (resort) // renderer.cu:459-460
+			check(acr_hip_sort_pixel_map(ctx, acr_hip_path_keys(ctx), acr_hip_pixel_map(ctx), dim.x * dim.y), "acr_hip_sort_pixel_map");
 		check(acr_hip_sync(ctx), "acr_hip_sync"); // cudaDeviceSynchronize (renderer.cu:422)
 		framesNoMove++;
 	}

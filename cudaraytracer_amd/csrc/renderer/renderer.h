@@ -45,6 +45,10 @@ namespace acr
 		void setMaxBounces(uint32_t n) { maxBounces = n; }
 		void setFixedSeed(long long seed) { fixedSeed = seed; } // < 0: rand()
 		void setCollectStats(bool on) { collectStats = on; }
+		// The reference's adaptive assignment (renderer.cu:343-355,391-392,457-461; disabled at its v0, so off by
+		// default): every `every` frames without a camera move the pixel table is re-sorted by the traversal-path keys
+		// of the frame just rendered; a move resets it to the identity.
+		void setAdaptiveAssignment(bool on, uint32_t every = 60) { adaptive = on; pixelMapFrameMod = every ? every : 60; }
 		void setCamera(const Camera &cam); // places the camera directly; restarts accumulation like a move
 		Camera getCamera() const;
 
@@ -68,6 +72,8 @@ namespace acr
 		uint32_t maxBounces = 5;
 		long long fixedSeed = -1;
 		bool collectStats = false;
+		bool adaptive = false;
+		uint32_t pixelMapFrameMod = 60; // renderer.cu:392
 		acr_hip_ctx *ctx = nullptr;
 	};
 } // namespace acr

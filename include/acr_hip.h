@@ -232,6 +232,11 @@ int acr_hip_read_hit_t(acr_hip_ctx *ctx, float *t, size_t count);
 int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats);
 /* device address of the context-owned framebuffer (NULL before acr_hip_resize) */
 void *acr_hip_framebuffer(acr_hip_ctx *ctx);
+/* device addresses of the context-owned pixel table (width*height ints, the identity after acr_hip_resize;
+ * DevParams::pixelValues, renderer.cu:19,133,137) and traversal-path keys (width*height uint64); NULL before
+ * acr_hip_resize.  Pass them as acr_frame::pixel_values_dev / path_keys_dev and to acr_hip_sort_pixel_map. */
+int32_t *acr_hip_pixel_map(acr_hip_ctx *ctx);
+uint64_t *acr_hip_path_keys(acr_hip_ctx *ctx);
 
 /* The reference's adaptive assignment step (renderer.cu:131-137,457-461; disabled at its v0): fills
  * pixel_values_dev[0..num_pixels) with the pixel numbers 0..num_pixels-1 stably sorted by their traversal-path

@@ -127,6 +127,8 @@ int acr_host_renderer_get_camera(const acr_host_renderer *r, acr_camera *cam);
 /* MAX_BOUNCES (renderer.cu:10) and the rand() seed source (application.cpp:76, renderer.cu:421):
  * fixed_seed >= 0 makes every frame use seed = fixed_seed + frame number instead of rand(). */
 int acr_host_renderer_configure(acr_host_renderer *r, uint32_t max_bounces, int64_t fixed_seed, uint32_t collect_stats);
+/* adaptive assignment of pixels to work-items (renderer.cu:343-355,457-461): off by default, like the reference at v0 */
+int acr_host_renderer_set_adaptive(acr_host_renderer *r, uint32_t on, uint32_t every);
 int acr_host_renderer_render(acr_host_renderer *r);                                          /* renderer.cu:397-423, waits like :422 */
 uint64_t acr_host_renderer_frames_no_move(const acr_host_renderer *r);
 int acr_host_renderer_read(acr_host_renderer *r, float *rgba, size_t num_floats, uint32_t *primid, float *hit_t);

@@ -79,3 +79,43 @@ def test_renderer_errors(acr):
         r.close()
     with pytest.raises(RuntimeError, match="GPU"):
         acr.Renderer(16, 16, device=9999)
+
+
+def test_adaptive_assignment_in_the_render_loop(acr, orc, built):
+    """Renderer with the reference's adaptive assignment switched on: every 3 still frames the pixel table is
+    re-sorted by the keys of the frame just rendered (renderer.cu:457-461), a camera move resets it
+    (renderer.cu:165,344-348).  The accumulated image equals the oracle's run through the same tables."""
+    b = built["cornell-box-cycles"]
+    w, h = 160, 96
+    n = w * h
+    r = acr.Renderer(w, h, samples=1, device=0)
+    try:
+        r.configure(max_bounces=3, fixed_seed=70)
+        r.set_adaptive(True, every=3)
+        r.load_scene(b.scene)
+
+        def run(frames, camera=None):
+            screen, table, tables = None, None, []
+            for f in range(frames):
+                r.render()
+                ref = b.oracle.render(w, h, seed=70 + f, frames=f, max_bounces=3, screen=screen, pixel_map=table, camera=camera)
+                screen = ref["screen"]
+                if f == 0:
+                    table = None  # frames == 0 renders through the identity and resets the table
+                if (f + 1) % 3 == 0:
+                    table = np.argsort(ref["path_key"].reshape(-1), kind="stable").astype(np.int32)
+                    tables.append(table)
+            img, _, _ = r.read()
+            assert np.array_equal(img.view(np.uint32), screen.view(np.uint32))
+            return tables
+
+        tables = run(8)
+        assert len(tables) == 2 and not np.array_equal(tables[0], np.arange(n))
+        pos, dr = (0.3, 0.2), (-0.08, 0.03)
+        r.move_camera(pos, dr)
+        cam = orc.OrcCamera()
+        orc.lib().orc_scene_camera(b.oracle.h, C.byref(cam))
+        orc.lib().orc_move_camera(C.byref(cam), (C.c_float * 2)(*pos), (C.c_float * 2)(*dr))
+        run(4, camera=cam)
+    finally:
+        r.close()

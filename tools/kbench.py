@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--aov", action="store_true", help="also write primitive ids and hit distances")
     ap.add_argument("--tag", default="")
     ap.add_argument("--nolights", action="store_true", help="drop the scene's lights (primary rays only)")
+    ap.add_argument("--accumulate", choices=["identity", "sorted"], default=None,
+                    help="time frames > 0 (running mean) through the identity pixel table or through the table sorted by traversal-path key")
     args = ap.parse_args()
     w, h = (int(v) for v in args.size.split("x"))
 
@@ -82,13 +84,32 @@ def main():
         digest += "/" + hashlib.sha1(prim.cpu().numpy().tobytes() + ht.cpu().numpy().tobytes()).hexdigest()[:16]
     rays = st.rays_primary + st.rays_shadow + st.rays_bounce
 
+    frames_of = lambda k: 0
+    if args.accumulate:
+        n = w * h
+        keys = torch.zeros(n, dtype=torch.int64, device=dev)
+        table = torch.arange(n, dtype=torch.int32, device=dev)
+        kw["pixel_values_dev"] = C.c_void_p(table.data_ptr())
+        core.render(w, h, seed=777, frames=0, max_bounces=args.bounces, path_keys_dev=C.c_void_p(keys.data_ptr()), **kw)
+        if args.accumulate == "sorted":
+            t0 = time.perf_counter()
+            core.sort_pixel_map(C.c_void_p(keys.data_ptr()), C.c_void_p(table.data_ptr()), n)
+            torch.cuda.synchronize()
+            print("sort ms (first call, with allocation):", 1e3 * (time.perf_counter() - t0), file=sys.stderr)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            core.sort_pixel_map(C.c_void_p(keys.data_ptr()), C.c_void_p(table.data_ptr()), n)
+            e1.record()
+            torch.cuda.synchronize()
+            print("sort ms:", e0.elapsed_time(e1), file=sys.stderr)
+        frames_of = lambda k: 1 + k
     for k in range(5):
-        core.render(w, h, seed=1000 + k, frames=0, max_bounces=args.bounces, **kw)
+        core.render(w, h, seed=1000 + k, frames=frames_of(k), max_bounces=args.bounces, **kw)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for k, (a, b) in enumerate(evs):
         a.record()
-        core.render(w, h, seed=2000 + k, frames=0, max_bounces=args.bounces, **kw)
+        core.render(w, h, seed=2000 + k, frames=frames_of(5 + k), max_bounces=args.bounces, **kw)
         b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in evs])
