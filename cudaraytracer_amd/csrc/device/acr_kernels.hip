@@ -462,14 +462,22 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // three to four orders of magnitude above fp32 rounding, so the reference's
 // own mesh box test (geometry.cu:55) would fail for every mesh and the call
 // would return false with `info` untouched: returning false here is the same
-// result without the two matrix transforms.  The test ignores info.t on
-// purpose (a box beyond the current hit must still report `intersected`).
-// The host sets the flag only for rotation * uniform scale transforms, where
-// the reference's local ray is the true image of the world ray.
+// result without the two matrix transforms.  The host sets the flag only for
+// rotation * uniform scale transforms, where the reference's local ray is the
+// true image of the world ray.
+// `tLimit` also drops an object whose grown box the ray enters no nearer than
+// tLimit: the world-space t of any hit in it (scene.cu:431) exceeds that entry
+// distance by at least the margin, so with tLimit = info.t it could not replace
+// info (scene.cu:432).  The call would still return true there, so the caller
+// passes info.t only when that return value can no longer matter (a shadow
+// ray, or `intersected` already set) AND the ray direction has unit length, so
+// that slab distances are world distances like info.t (primary and shadow
+// rays are normalised; diffuse bounce directions are not, math.h:188-192);
+// FLT_MAX otherwise.
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
 template <bool FULL, bool FAST, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, float *undoMesh, bool &bail)
+                                                WorldHit &info, float *undoMesh, bool &bail, float tLimit)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
@@ -478,12 +486,12 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
 		if constexpr (FAST) {
 			const Interval wb = boxInterval(saWorld, wmin, wmax);
-			if (!intervalHit(wb.tmin, wb.tmax, FLT_MAX))
+			if (!intervalHit(wb.tmin, wb.tmax, tLimit))
 				return false;
 		} else {
 			SlabBox wb;
 			wb.init(saWorld, wmin, wmax);
-			if (!slabTest(wb.nearT, wb.farT, FLT_MAX))
+			if (!slabTest(wb.nearT, wb.farT, tLimit))
 				return false;
 		}
 	}
@@ -557,7 +565,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
 template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               float *undoScene, float *undoMesh, bool &bail, PathRec *path = nullptr)
+                                               float *undoScene, float *undoMesh, bool &bail, PathRec *path = nullptr, bool unitDir = false)
 {
 	SlabArgs sa;
 	sa.init(r);
@@ -573,7 +581,7 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
 	auto leaf = [&](uint32_t start, uint32_t end) {
 		for (uint32_t i = start; i < end; i++) {
-			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, undoMesh, bail);
+			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, undoMesh, bail, (unitDir && (SHADOW || intersected)) ? info.t : FLT_MAX);
 			if constexpr (FAST) {
 				if (bail) return true;
 			}
@@ -676,7 +684,7 @@ __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc
 			WorldHit sh;
 			sh.t = t;
 			cnt.shadow++;
-			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, undoScene, undoMesh, bail))
+			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, undoScene, undoMesh, bail, nullptr, true))
 				c = vec3(0, 0, 0);
 			if constexpr (FAST) {
 				if (bail) return light;
@@ -817,10 +825,10 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if constexpr (KEYS) {
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
-			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, &pathRec);
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, &pathRec, true);
 			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
 		} else {
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, nullptr, level == 0);
 		}
 		if (FAST && bail) break;
 		if (!hit)
