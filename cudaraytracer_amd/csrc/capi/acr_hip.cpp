@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../../include/acr_hip.h"
+#include "../math/math.h"
 #include "../device/device_scene.h"
 #include "../device/render_params.h"
 
@@ -579,6 +580,19 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	memcpy(p.cam_position, ctx->camera.position, 12);
 	memcpy(p.cam_forward, ctx->camera.forward, 12);
 	memcpy(p.cam_up, ctx->camera.up, 12);
+	{
+		// renderer.cu:197-200,360-361 with the operations of csrc/math/math.h (this file is built with -ffp-contract=off)
+		using namespace acr::math;
+		const vec3 dir(p.cam_forward[0], p.cam_forward[1], p.cam_forward[2]);
+		const vec3 up(p.cam_up[0], p.cam_up[1], p.cam_up[2]);
+		const vec3 cR = cross(dir, up);
+		const vec3 cU = cross(cR, dir);
+		p.cam_cr[0] = cR.x; p.cam_cr[1] = cR.y; p.cam_cr[2] = cR.z;
+		p.cam_cu[0] = cU.x; p.cam_cu[1] = cU.y; p.cam_cu[2] = cU.z;
+		p.cam_dist = fastertanfull(p.cam_hfov / 2.0f);
+		p.inv_width = 1.0f / int(f->width);
+		p.inv_height = 1.0f / int(f->height);
+	}
 	p.width = f->width;
 	p.height = f->height;
 	p.blocks_x = (f->width + 15) / 16;

@@ -695,15 +695,17 @@ __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc
 	return light;
 }
 
-// get_pixel_dir (renderer.cu:184-206)
+// get_pixel_dir (renderer.cu:184-206).  Its camera-only part -- cR = cross(dir, up), cU = cross(cR, dir),
+// dist = fastertanfull(hFOV / 2) (renderer.cu:197-200) -- is the same for every pixel and is evaluated once on
+// the host with the same single-operation arithmetic (cameraBasis in render_params.h); the per-pixel
+// expression keeps the reference's association.
 __device__ __forceinline__ vec3 getPixelDir(const RenderParams &p, float ni, float nj)
 {
 	const vec3 dir(p.cam_forward[0], p.cam_forward[1], p.cam_forward[2]);
-	const vec3 up(p.cam_up[0], p.cam_up[1], p.cam_up[2]);
 	const float AR = p.cam_aspect;
-	const vec3 cR = cross(dir, up);
-	const vec3 cU = cross(cR, dir);
-	const float dist = fastertanfull(p.cam_hfov / 2.0f);
+	const vec3 cR(p.cam_cr[0], p.cam_cr[1], p.cam_cr[2]);
+	const vec3 cU(p.cam_cu[0], p.cam_cu[1], p.cam_cu[2]);
+	const float dist = p.cam_dist;
 	return normalize(dir + dist * (nj * cU + AR * ni * cR));
 }
 
@@ -775,24 +777,27 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 	if (!res.active)
 		return res;
 
-	const int width = int(p.width), height = int(p.height);
+	const int width = int(p.width);
 	const int oldIndex = int(oldx) + width * int(oldy);
-	int index;
-	if (p.frames == 0) { // renderer.cu:344-352
+	int index, x, y;
+	if (p.frames == 0 || !p.pixel_values) { // renderer.cu:344-352
 		if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
 		index = oldIndex;
+		// index % width and index / width (renderer.cu:354-355) of oldx + width * oldy with oldx < width
+		x = int(oldx);
+		y = int(oldy);
 	} else {
-		index = p.pixel_values ? p.pixel_values[oldIndex] : oldIndex;
+		index = p.pixel_values[oldIndex];
+		x = index % width;
+		y = index / width;
 	}
-	const int x = index % width;
-	const int y = index / width;
 	if (!tiled) outSlot = size_t(index);
 
 	RandState state;
 	randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
 
-	const float dx = 1.0f / width;
-	const float dy = 1.0f / height;
+	const float dx = p.inv_width;  // 1.0f / width, 1.0f / height (renderer.cu:360-361), divided once on the host
+	const float dy = p.inv_height;
 	const float i = 2.0f * (float(x) + randUniform(state)) * dx - 1.0f;
 	const float j = 2.0f * (float(y) + randUniform(state)) * dy - 1.0f;
 

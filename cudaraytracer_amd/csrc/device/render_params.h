@@ -25,6 +25,9 @@ namespace dev
 		// camera (camera.h:14-16), aspect already set to width/height (renderer.cu:179)
 		float cam_aspect, cam_hfov;
 		float cam_position[3], cam_forward[3], cam_up[3];
+		// the camera-only terms of get_pixel_dir (renderer.cu:197-200) and of the pixel step (renderer.cu:360-361)
+		float cam_cr[3], cam_cu[3], cam_dist;
+		float inv_width, inv_height;
 		// frame
 		uint32_t width, height;
 		uint32_t blocks_x;          // ceil(width / 16), full-frame mode
