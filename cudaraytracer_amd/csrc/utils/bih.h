@@ -52,12 +52,18 @@ namespace acr
 			std::vector<uint32_t> ord(hObjs.size());
 			for (size_t i = 0; i < ord.size(); i++) ord[i] = uint32_t(i);
 			Build b{this, hObjs, ord, data};
+			// The two recursive calls of sift() work on disjoint item ranges and disjoint subtrees, so large
+			// builds run them as parallel tasks; every node sees the same items in the same order as in a
+			// serial build, so the tree and the permutation are identical.
+#pragma omp parallel if (hObjs.size() >= kParallelBuildItems)
+#pragma omp single nowait
 			b.sift(0, boundingBox, 0, hObjs.size());
 			objs = vector<T>(hObjs);
 			order = ord;
 		}
 
 		const static size_t MAX_SIZE = (size_t(1) << MAX_DEPTH) - 1; // bih.h:89, for the default depth
+		const static size_t kParallelBuildItems = 1 << 15;           // subtrees with fewer items are built serially
 		size_t maxSize() const { return tree.size(); }
 		size_t maxDepth() const { return depth; }
 		const std::vector<Node> &nodes() const { return tree; }
@@ -139,8 +145,16 @@ namespace acr
 				node.axis = axis;
 				node.defined |= 2;
 
-				const bool left = sift(2 * index + 1, lBB, start, size_t(lo));
-				const bool right = sift(2 * index + 2, rBB, size_t(lo), end);
+				bool left, right;
+				if (end - start >= kParallelBuildItems) {
+#pragma omp task shared(left) firstprivate(index, lBB, start, lo)
+					left = sift(2 * index + 1, lBB, start, size_t(lo));
+					right = sift(2 * index + 2, rBB, size_t(lo), end);
+#pragma omp taskwait
+				} else {
+					left = sift(2 * index + 1, lBB, start, size_t(lo));
+					right = sift(2 * index + 2, rBB, size_t(lo), end);
+				}
 				// a node is a leaf as soon as EITHER child is missing or empty (bih.h:203-205)
 				self->tree[index].isLeaf = uint8_t(left || right);
 				self->tree[index].defined |= 4;

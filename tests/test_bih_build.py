@@ -74,7 +74,8 @@ def test_shipped_scenes_product_equals_oracle(built, name):
     check_scene(built[name])
 
 
-@pytest.mark.parametrize("ntri,depth", [(1, 6), (2, 1), (7, 3), (100, 6), (1000, 6), (5000, 10), (20000, 14)])
+@pytest.mark.parametrize("ntri,depth", [(1, 6), (2, 1), (7, 3), (100, 6), (1000, 6), (5000, 10), (20000, 14),
+                                        (150000, 16)])  # the last one is large enough for the product's task-parallel build
 def test_soup_product_equals_oracle(acr, orc, ntri, depth):
     b = Built(acr, orc, soup_data(acr, ntri, seed=ntri + depth), scene_depth=6, mesh_depth=depth)
     check_scene(b)
