@@ -66,6 +66,8 @@ struct acr_hip_ctx
 	uint32_t *redoList = nullptr;
 	size_t redoCap = 0;
 	uint32_t redoParity = 0;
+	float2 *meshGlob = nullptr;    // global part of the mesh tree's waiting-child column (deep trees only)
+	size_t meshGlobBytes = 0;
 	uint32_t sceneDepthGiven = 0;  // MAX_DEPTH of the scene tree as uploaded (before unused levels were trimmed)
 	// scratch of acr_hip_sort_pixel_map
 	void *sortTemp = nullptr;
@@ -187,15 +189,30 @@ namespace
 		int ldsMode;
 		uint32_t stackSlot;
 		size_t ldsBytes;
+		uint32_t cstackOff;       // floats from the first column to the direct-term columns
+		uint32_t meshGlobLevels;  // top levels of the mesh tree's waiting-child column kept in global memory
 	};
 
-	// Decides how much of the scene a workgroup stages into LDS.
-	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels)
+	// Decides how much of the scene a workgroup stages into LDS and how the per-lane columns are laid out.
+	// splitDeepColumns: false for kernels that keep every level of the waiting-child column in LDS (traceKernel).
+	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns)
 	{
-		// two floats per tree level and lane (the interval traversal's waiting-child column; the six-plane
-		// traversal uses one of them as its undo column), three per bounce level for the direct terms
-		const size_t stackFloats = size_t(2 * (h.scene_depth + h.max_mesh_depth) + 3 * colorLevels) * kBlock;
-		const size_t stackBytes = stackFloats * 4;
+		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
+		// six-plane traversal's undo column (the list pass runs in the same LDS block).  A deep mesh tree keeps
+		// only its deepest levels' waiting-child entries in LDS, so that the columns stay within what lets four
+		// workgroups share a CU (the kernel's register budget allows four); the levels above go to global memory.
+		constexpr size_t kColumnBudget = 30 * 1024;
+		uint32_t meshLdsLevels = h.max_mesh_depth;
+		const size_t perLevel = size_t(2) * kBlock * 4;
+		if (splitDeepColumns && (h.scene_depth + meshLdsLevels) * perLevel > kColumnBudget) {
+			const size_t fit = kColumnBudget / perLevel;
+			meshLdsLevels = fit > h.scene_depth + 4 ? uint32_t(fit - h.scene_depth) : 4u;
+			if (meshLdsLevels > h.max_mesh_depth) meshLdsLevels = h.max_mesh_depth;
+		}
+		const size_t intervalFloats = size_t(2) * (h.scene_depth + meshLdsLevels);
+		const size_t sixPlaneFloats = size_t(h.scene_depth) + h.max_mesh_depth;
+		const size_t columnFloats = (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) * kBlock;
+		const size_t stackBytes = (columnFloats + size_t(3) * colorLevels * kBlock) * 4;
 		LaunchPlan p;
 		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {
 			p.ldsMode = 2;
@@ -208,6 +225,8 @@ namespace
 			p.stackSlot = 0;
 		}
 		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
+		p.cstackOff = uint32_t(columnFloats);
+		p.meshGlobLevels = h.max_mesh_depth - meshLdsLevels;
 		return p;
 	}
 	// Makes list.dev hold `ids`.  A list equal to the previous one costs a memcmp; a new one waits for the
@@ -268,6 +287,7 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->counters);
 	(void)hipFree(ctx->redoCount);
 	(void)hipFree(ctx->redoList);
+	(void)hipFree(ctx->meshGlob);
 	(void)hipFree(ctx->sortTemp);
 	(void)hipFree(ctx->sortKeysOut);
 	(void)hipFree(ctx->sortValuesIn);
@@ -615,17 +635,31 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	if (p.tile_rays) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_rays, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 	if (p.tile_cycles) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_cycles, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0);
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true);
 	p.lds_stack_slot = plan.stackSlot;
+	p.lds_cstack_off = plan.cstackOff;
 	const bool fast = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO;
+	if (fast && plan.meshGlobLevels) {
+		const size_t slots = size_t(grid) * kBlock;
+		if (slots >= (1ull << 32)) return fail(ctx, ACR_ERR_UNSUPPORTED, "launch too large for a mesh tree this deep");
+		const size_t need = slots * plan.meshGlobLevels * sizeof(float2);
+		if (ctx->meshGlobBytes < need) {
+			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			(void)hipFree(ctx->meshGlob);
+			ctx->meshGlob = nullptr;
+			ctx->meshGlobBytes = 0;
+			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->meshGlob), need));
+			ctx->meshGlobBytes = need;
+		}
+		p.mesh_glob = ctx->meshGlob;
+		p.mesh_glob_levels = plan.meshGlobLevels;
+		p.mesh_glob_stride = uint32_t(slots);
+	}
 	if (fast) {
 		const size_t slots = size_t(grid) * kBlock;
 		if (ctx->redoCap < slots) {
 			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 			(void)hipFree(ctx->redoList);
-	(void)hipFree(ctx->sortTemp);
-	(void)hipFree(ctx->sortKeysOut);
-	(void)hipFree(ctx->sortValuesIn);
 			ctx->redoList = nullptr;
 			ctx->redoCap = 0;
 			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->redoList), slots * sizeof(uint32_t)));
@@ -684,7 +718,7 @@ int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const
 		p.n = n;
 		p.origins = dO; p.dirs = dD; p.tmax = tmax ? dTmax : nullptr;
 		p.hit = dHit; p.t = dT; p.prim = dPrim; p.position = dPos; p.normal = dNrm;
-		const LaunchPlan plan = planLds(ctx->header, 0);
+		const LaunchPlan plan = planLds(ctx->header, 0, false);
 		p.lds_stack_slot = plan.stackSlot;
 		e = acr_dev_launch_trace(&p, plan.ldsMode, (ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO) ? 1 : 0, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
 	}

@@ -58,6 +58,7 @@ __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 template <bool SMALL_LDS, bool LARGE_LDS>
 struct SceneMem
 {
+	static constexpr bool kLargeInLds = LARGE_LDS;
 	const uint4 *__restrict__ g;
 	__device__ __forceinline__ uint4 small(uint32_t slot) const
 	{
@@ -275,12 +276,34 @@ __device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &m
 }
 __device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) { return tmin <= tmax && tmin < tcur && tmax > epsilon(); }
 
-// bih.h:209-299 on intervals.  `stack` is this lane's column: stack[level * kBlock].
+// The waiting-child column of one tree and lane: one float2 per tree level.  The deepest `ldsLevels` levels,
+// where a traversal spends nearly all of its pushes and pops, live in LDS (entry for level l at
+// lds[(l - globLevels) * kBlock]); the levels above them, which a ray touches at most once each, live in a
+// global-memory column (glob[l * globStride], neighbouring lanes in neighbouring addresses).  globLevels is 0
+// for every tree shallow enough for LDS, which is all trees but the deep single-mesh ones.
+struct LevelColumn
+{
+	float2 *lds;
+	float2 *glob;
+	uint32_t globLevels, globStride;
+	__device__ __forceinline__ void store(uint32_t level, float2 v) const
+	{
+		if (level >= globLevels) lds[(level - globLevels) * kBlock] = v;
+		else glob[size_t(level) * globStride] = v;
+	}
+	__device__ __forceinline__ float2 load(uint32_t level) const
+	{
+		if (level >= globLevels) return lds[(level - globLevels) * kBlock];
+		return glob[size_t(level) * globStride];
+	}
+};
+
+// bih.h:209-299 on intervals.  `stack` is this lane's waiting-child column.
 // Loop shape: an inner loop that only descends (a lane leaves it at a leaf, or when its traversal has
 // nothing left), then the leaf's items, then the pop.  Lanes of a wave therefore do their node steps
 // together and their item tests together instead of interleaving the two.
 template <bool KEYS = false, class LoadNode, class Leaf, class TCur>
-__device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, float2 *stack, Leaf leaf, TCur tcur,
+__device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArgs &sa, Interval box, const LevelColumn &stack, Leaf leaf, TCur tcur,
                                                 PathRec *path = nullptr)
 {
 	uint32_t idx = 0, level = 0, pending = 0;
@@ -311,7 +334,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 				const bool takeFarSide = hitL ? sg : !sg;
 				if (hitL && hitR) {
 					pending |= 1u << level;
-					stack[level * kBlock] = takeFarSide ? make_float2(tminB, nearSideMax) : make_float2(farSideMin, tmaxB);
+					stack.store(level, takeFarSide ? make_float2(tminB, nearSideMax) : make_float2(farSideMin, tmaxB));
 				}
 				if (takeFarSide) tminB = farSideMin;
 				else tmaxB = nearSideMax;
@@ -325,7 +348,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 				}
 				const uint32_t l = 31u - uint32_t(__clz(int(pending)));
 				pending &= ~(1u << l);
-				const float2 b = stack[l * kBlock];
+				const float2 b = stack.load(l);
 				tminB = b.x;
 				tmaxB = b.y;
 				idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2; // right child of this path's node on level l
@@ -341,7 +364,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 			return;
 		const uint32_t l = 31u - uint32_t(__clz(int(pending)));
 		pending &= ~(1u << l);
-		const float2 b = stack[l * kBlock];
+		const float2 b = stack.load(l);
 		tminB = b.x;
 		tmaxB = b.y;
 		idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2;
@@ -390,6 +413,15 @@ __device__ __forceinline__ mat3 loadMat3(const Mem &mem, uint32_t slot, uint32_t
 	return m;
 }
 
+// This lane's per-level LDS columns of the scene tree and of the mesh tree (floats for the six-plane form's undo
+// log, float2 for the interval form), and where the mesh column continues in global memory.
+struct Columns
+{
+	float *scene, *mesh;
+	float2 *meshGlob;
+	uint32_t meshGlobLevels, meshGlobStride;
+};
+
 // Face::intersect (geometry.h:123-146) for the items [start, end) of a leaf
 template <class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
@@ -398,7 +430,7 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // Mesh::intersect (geometry.cu:52-61) for a local-space ray
 template <bool FAST, class Mem>
 __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, uint32_t meshId, const Ray &lr,
-                                              const SlabArgs &sa, LocalHit &tmp, float *stackMesh)
+                                              const SlabArgs &sa, LocalHit &tmp, const Columns &col)
 {
 	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
 	const uint4 q0 = mem.small(ms), q1 = mem.small(ms + 1), q2 = mem.small(ms + 2);
@@ -417,13 +449,14 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 		const Interval root = boxInterval(sa, bmin, bmax);
 		if (!intervalHit(root.tmin, root.tmax, tmp.t))
 			return false;
-		bihTraverseFast(loadNode, sa, root, reinterpret_cast<float2 *>(stackMesh), leaf, tcur);
+		const LevelColumn lc = {reinterpret_cast<float2 *>(col.mesh), col.meshGlob, col.meshGlobLevels, col.meshGlobStride};
+		bihTraverseFast(loadNode, sa, root, lc, leaf, tcur);
 	} else {
 		SlabBox root;
 		root.init(sa, bmin, bmax);
 		if (!slabTest(root.nearT, root.farT, tmp.t))
 			return false;
-		bihTraverse(loadNode, q2.y, sa, root, stackMesh, leaf, tcur);
+		bihTraverse(loadNode, q2.y, sa, root, col.mesh, leaf, tcur);
 	}
 	if (intersected) {
 		tmp.material = q0.w;
@@ -477,7 +510,7 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
 template <bool FULL, bool FAST, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, float *undoMesh, bool &bail, float tLimit)
+                                                WorldHit &info, const Columns &col, bool &bail, float tLimit)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
@@ -524,7 +557,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		const uint4 ids = mem.small(idSlot);
 		const uint32_t sel = (meshBegin + k) & 3u;
 		const uint32_t meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
-		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, undoMesh);
+		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, col);
 	}
 
 	if (intersected) {
@@ -565,7 +598,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
 template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               float *undoScene, float *undoMesh, bool &bail, PathRec *path = nullptr, bool unitDir = false)
+                                               const Columns &col, bool &bail, PathRec *path = nullptr, bool unitDir = false)
 {
 	SlabArgs sa;
 	sa.init(r);
@@ -581,7 +614,7 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
 	auto leaf = [&](uint32_t start, uint32_t end) {
 		for (uint32_t i = start; i < end; i++) {
-			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, undoMesh, bail, (unitDir && (SHADOW || intersected)) ? info.t : FLT_MAX);
+			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (unitDir && (SHADOW || intersected)) ? info.t : FLT_MAX);
 			if constexpr (FAST) {
 				if (bail) return true;
 			}
@@ -596,11 +629,12 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	};
 	auto tcur = [&]() { return info.t; };
 	if constexpr (FAST) {
-		bihTraverseFast<KEYS>(loadNode, sa, boxInterval(sa, smin, smax), reinterpret_cast<float2 *>(undoScene), leaf, tcur, path);
+		const LevelColumn lc = {reinterpret_cast<float2 *>(col.scene), nullptr, 0u, 0u};
+		bihTraverseFast<KEYS>(loadNode, sa, boxInterval(sa, smin, smax), lc, leaf, tcur, path);
 	} else {
 		SlabBox root;
 		root.init(sa, smin, smax);
-		bihTraverse<KEYS>(loadNode, sc.scene_depth, sa, root, undoScene, leaf, tcur, path);
+		bihTraverse<KEYS>(loadNode, sc.scene_depth, sa, root, col.scene, leaf, tcur, path);
 	}
 	return SHADOW ? occluded : intersected;
 }
@@ -637,7 +671,7 @@ struct Counters
 // Scene::lightPoint (scene.cu:273-292) with pointLightAccum (209-231) and spotLightAccum (234-271)
 template <bool FAST, class Mem>
 __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc, const vec3 &pos, const vec3 &norm, RandState &state,
-                                           Counters &cnt, float *undoScene, float *undoMesh, bool &bail)
+                                           Counters &cnt, const Columns &col, bool &bail)
 {
 	vec3 light(0, 0, 0);
 	for (uint32_t i = 0; i < sc.num_lights; i++) {
@@ -684,7 +718,7 @@ __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc
 			WorldHit sh;
 			sh.t = t;
 			cnt.shadow++;
-			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, undoScene, undoMesh, bail, nullptr, true))
+			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, col, bail, nullptr, true))
 				c = vec3(0, 0, 0);
 			if constexpr (FAST) {
 				if (bail) return light;
@@ -743,9 +777,14 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 {
 	const SceneHeader &sc = p.scene;
 	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
-	float *undoScene = ldsF + (FAST ? 2 : 1) * threadIdx.x;
-	float *undoMesh = undoScene + (FAST ? 2 : 1) * sc.scene_depth * kBlock;
-	float *cstack = ldsF + 2 * (sc.scene_depth + sc.max_mesh_depth) * kBlock + threadIdx.x;
+	Columns col;
+	col.scene = ldsF + (FAST ? 2 : 1) * threadIdx.x;
+	col.mesh = col.scene + (FAST ? 2 : 1) * sc.scene_depth * kBlock;
+	// a scene staged whole into LDS has no tree deep enough for the global part: a compile-time zero there
+	col.meshGlobLevels = (FAST && !Mem::kLargeInLds) ? p.mesh_glob_levels : 0u;
+	col.meshGlobStride = p.mesh_glob_stride;
+	col.meshGlob = p.mesh_glob + (size_t(blockIdx.x) * kBlock + threadIdx.x);
+	float *cstack = ldsF + p.lds_cstack_off + threadIdx.x;
 
 	// which pixel slot: 16x16 pixels per workgroup, 8x8 per wave
 	const uint32_t lane = vtid & 63u, wave = vtid >> 6;
@@ -830,10 +869,10 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if constexpr (KEYS) {
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
-			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, &pathRec, true);
-			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail);
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, true);
+			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail);
 		} else {
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, undoScene, undoMesh, bail, nullptr, level == 0);
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0);
 		}
 		if (FAST && bail) break;
 		if (!hit)
@@ -844,7 +883,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 			cnt.primaryHits++;
 		}
 		// direct illum (renderer.cu:247-248); the material record is fetched after the shadow rays
-		const vec3 lightSum = lightPoint<FAST>(mem, sc, info.position, info.normal, state, cnt, undoScene, undoMesh, bail);
+		const vec3 lightSum = lightPoint<FAST>(mem, sc, info.position, info.normal, state, cnt, col, bail);
 		if (FAST && bail) break;
 		const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
 		const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
@@ -1052,8 +1091,8 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 		info.prim = 0xFFFFFFFFu;
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
-		float *undoScene = ldsF + 2 * threadIdx.x;
-		h = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, undoScene, undoScene + 2 * sc.scene_depth * kBlock, bail);
+		const Columns col = {ldsF + 2 * threadIdx.x, ldsF + 2 * threadIdx.x + 2 * sc.scene_depth * kBlock, nullptr, 0u, 0u};
+		h = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail);
 	}
 	if (bail) {
 		info.t = p.tmax ? p.tmax[i] : FLT_MAX;
@@ -1062,8 +1101,8 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
 		bool unused = false;
-		float *undoScene = ldsF + threadIdx.x;
-		h = sceneIntersect<false, false>(mem, sc, r, info, 0.0f, undoScene, undoScene + sc.scene_depth * kBlock, unused);
+		const Columns col = {ldsF + threadIdx.x, ldsF + threadIdx.x + sc.scene_depth * kBlock, nullptr, 0u, 0u};
+		h = sceneIntersect<false, false>(mem, sc, r, info, 0.0f, col, unused);
 	}
 	p.hit[i] = h ? 1 : 0;
 	p.t[i] = info.t;

@@ -45,6 +45,12 @@ namespace dev
 		uint32_t *tile_rays;          // device [num_tiles] or null
 		uint32_t *tile_cycles;        // device [num_tiles] or null
 		uint32_t lds_stack_slot;    // first LDS slot after the staged scene
+		uint32_t lds_cstack_off;    // floats from there to the per-bounce-level direct-term columns
+		// Interval traversal of deep mesh trees: the top mesh_glob_levels levels of the waiting-child column live in
+		// global memory (mesh_glob[level * mesh_glob_stride + slot], slot = workgroup * ACR_BLOCK + work-item), the
+		// levels below them in LDS.  0 levels for trees that fit LDS whole.
+		uint32_t mesh_glob_levels, mesh_glob_stride;
+		float2 *mesh_glob;
 		// Pixels the interval-traversal launch cannot serve: their slot numbers (workgroup * 256 + work-item) are
 		// appended here and rendered by the six-plane list pass that follows in the stream.
 		uint32_t *redo_count;       // device: entries in redo_list (this frame)
