@@ -48,6 +48,10 @@ constexpr int kBlock = ACR_BLOCK;
 #ifndef ACR_RENDER_WAVES
 #define ACR_RENDER_WAVES 4
 #endif
+// the same for scenes whose trees and triangles are read from HBM (memory latency, not VALU issue, bounds those)
+#ifndef ACR_RENDER_WAVES_HBM
+#define ACR_RENDER_WAVES_HBM 5
+#endif
 
 extern __shared__ uint4 g_lds[];
 
@@ -1004,7 +1008,7 @@ __device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotRe
 // One work-item per pixel slot of the frame (or of the listed tiles).
 // FAST: interval traversal; pixels it cannot serve are appended to p.redo_list for renderListKernel.
 template <bool SMALL_LDS, bool LARGE_LDS, bool FAST, bool KEYS>
-__global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES) renderKernel(const RenderParams p)
+__global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_RENDER_WAVES_HBM) renderKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
 	SceneMem<SMALL_LDS, LARGE_LDS> mem;
