@@ -8,22 +8,28 @@
 // Everything here follows the reference's arithmetic operation for operation
 // (citations are file:line relative to the reference root); what differs is
 // the machinery around it:
-//   * BIH traversal keeps no box stack.  The reference pushes whole clipped
-//     boxes (bih.h:214-215,256,262).  Here a lane carries the six slab
-//     distances (bound - o) * invD of its CURRENT box in registers, replaces
-//     one of them per descent, and logs the replaced value in an LDS "undo"
-//     column (one float per tree level per lane).  A bitmask remembers at
-//     which levels the right child passed its slab test and is still to be
-//     visited; popping walks the heap index up to that level, restoring one
-//     value per level.  Each slab distance is the same single subtract and
-//     multiply the reference performs (geometry.h:52-66), so every compare
-//     sees identical bits and the visit order (left before right, deepest
-//     pending first, leaf items ascending; bih.h:253-288) is unchanged.
+//   * BIH traversal keeps no box stack (the reference pushes whole clipped
+//     boxes, bih.h:214-215,256,262).  Two forms of the same traversal:
+//       - interval form (the default): a lane carries max(near) / min(far) of
+//         its current box, two floats, and the right child that waits while the
+//         left subtree is walked is two floats in a per-level LDS column; see
+//         the comment above `struct Interval` for why every decision is the
+//         reference's;
+//       - six-plane form: the slab test compare for compare (geometry.h:44-76)
+//         on the six distances (bound - o) * invD kept in registers, one of
+//         them replaced per descent and logged in an LDS "undo" column.  It
+//         serves the pixels whose rays the interval form cannot (list pass),
+//         and whole frames on request.
+//     A bitmask remembers at which levels the right child passed its test and
+//     is still to be visited (left before right, deepest pending first, leaf
+//     items ascending; bih.h:253-288).
 //   * rayColor's template recursion (renderer.cu:232-324) is a loop; the
 //     per-level direct terms are kept in an LDS column and summed from the
 //     deepest level outwards, the order the recursion adds them.
 //   * Shadow rays stop at the first object that proves occlusion; see
 //     sceneIntersect for why that cannot change the result.
+//   * Optionally the per-pixel traversal-path key of the reference's adaptive
+//     assignment (bih.h:13-27,268-274) is recorded (KEYS).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include <hip/hip_runtime.h>
