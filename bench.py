@@ -317,8 +317,9 @@ def main():
                     sample = f"rows {r0}..{r1 - 1} of one {WIDTH}x{HEIGHT} frame of the same workload ({t_cpu:.1f} s)"
                 tc = time.perf_counter()
                 rr = max(1, (r1 - r0) // 16)
+                m0 = (r0 + r1 - rr) // 2  # rows from the middle of the sample: the top rows of a frame are mostly background
                 c1 = o.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=1, aov=False, camera=cam0,
-                              row_begin=r0, row_end=r0 + rr)["counters"]
+                              row_begin=m0, row_end=m0 + rr)["counters"]
                 t1 = time.perf_counter() - tc
                 out["cpu_baseline"] = {"value": cpu_rays / t_cpu / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                        "sample": sample, "value_1core": (c1["rays_primary"] + c1["rays_shadow"] + c1["rays_bounce"]) / t1 / 1e6,
