@@ -194,7 +194,8 @@ namespace
 	};
 
 	// Decides how much of the scene a workgroup stages into LDS and how the per-lane columns are laid out.
-	// splitDeepColumns: false for kernels that keep every level of the waiting-child column in LDS (traceKernel).
+	// splitDeepColumns: false for traceKernel, which keeps every level of the waiting-child column in LDS and
+	// needs room for the six-plane form's columns next to them.
 	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns)
 	{
 		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
@@ -211,7 +212,8 @@ namespace
 		}
 		const size_t intervalFloats = size_t(2) * (h.scene_depth + meshLdsLevels);
 		const size_t sixPlaneFloats = size_t(h.scene_depth) + h.max_mesh_depth;
-		const size_t columnFloats = (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) * kBlock;
+		// render launches run one form at a time in a workgroup and share the region; traceKernel runs both side by side
+		const size_t columnFloats = (splitDeepColumns ? (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) : intervalFloats + sixPlaneFloats) * kBlock;
 		const size_t stackBytes = (columnFloats + size_t(3) * colorLevels * kBlock) * 4;
 		LaunchPlan p;
 		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {

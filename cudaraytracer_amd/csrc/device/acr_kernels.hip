@@ -1111,7 +1111,10 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
 		bool unused = false;
-		const Columns col = {ldsF + threadIdx.x, ldsF + threadIdx.x + sc.scene_depth * kBlock, nullptr, 0u, 0u};
+		// Other waves of this workgroup may still be in the interval form: the undo columns of the six-plane form
+		// get their own LDS region behind the waiting-child columns (FAST), or start at the front (not FAST).
+		float *base = ldsF + (FAST ? 2 * (sc.scene_depth + sc.max_mesh_depth) * kBlock : 0) + threadIdx.x;
+		const Columns col = {base, base + sc.scene_depth * kBlock, nullptr, 0u, 0u};
 		h = sceneIntersect<false, false>(mem, sc, r, info, 0.0f, col, unused);
 	}
 	p.hit[i] = h ? 1 : 0;

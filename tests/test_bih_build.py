@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import Built, soup_data
+from conftest import Built, random_instanced_scene, soup_data
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -79,6 +79,12 @@ def test_shipped_scenes_product_equals_oracle(built, name):
 def test_soup_product_equals_oracle(acr, orc, ntri, depth):
     b = Built(acr, orc, soup_data(acr, ntri, seed=ntri + depth), scene_depth=6, mesh_depth=depth)
     check_scene(b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_instanced_scenes_product_equals_oracle(acr, orc, seed):
+    """nested parents, non-uniform scales, several meshes per object, 40 objects in a depth-6 tree"""
+    check_scene(Built(acr, orc, random_instanced_scene(acr, seed)))
 
 
 def test_reference_bih_printouts(built):

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import Built, soup_data
+from conftest import Built, random_instanced_scene, soup_data
 
 pytestmark = pytest.mark.gpu
 
@@ -474,3 +474,32 @@ def test_traversal_path_keys_and_sorted_pixel_map(core, built):
     finally:
         core.set_traversal(six_plane_only=False)
         core.use_own_stream()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_instanced_scenes(core, acr, orc, seed):
+    """40 objects instancing a few meshes: nested parents, uniform and non-uniform scales (the conservative world-box
+    skip is off for the latter), one or two meshes per object, mirror-like and translucent materials, three lights,
+    scene-tree leaves that hold several objects.  Both forms of the slab test, 4 bounces."""
+    b = Built(acr, orc, random_instanced_scene(acr, seed))
+    load(core, b)
+    w, h = 256, 144
+    ref = b.oracle.render(w, h, seed=seed, frames=0, max_bounces=4)
+    assert ref["counters"]["primary_hits"] > 0.1 * w * h and ref["counters"]["rays_bounce"] > 0
+    try:
+        for six_plane in (False, True):
+            core.set_traversal(six_plane_only=six_plane)
+            img, pid, ht, st = render(core, w, h, seed=seed, frames=0, max_bounces=4)
+            assert_same(img, pid, ht, st, ref)
+    finally:
+        core.set_traversal(six_plane_only=False)
+    # raw Scene::intersect queries from inside the cloud, in every direction
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-4, 4, (2000, 3)).astype(np.float32)
+    d = rng.normal(size=(2000, 3)).astype(np.float32)
+    d[::7, 0] = 0.0  # some axis-parallel components
+    got, want = core.trace_rays(o, d), b.oracle.trace_rays(o, d)
+    for k in ("hit", "prim"):
+        assert np.array_equal(got[k], want[k])
+    for k in ("t", "position", "normal"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32))
