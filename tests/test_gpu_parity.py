@@ -503,3 +503,44 @@ def test_random_instanced_scenes(core, acr, orc, seed):
         assert np.array_equal(got[k], want[k])
     for k in ("t", "position", "normal"):
         assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32))
+
+
+def test_random_instanced_scene_modes(core, acr, orc):
+    """the same kind of scene through the other launch shapes: accumulation, traversal-path keys, a tile list"""
+    import torch
+    b = Built(acr, orc, random_instanced_scene(acr, 4))
+    load(core, b)
+    w, h = 208, 112
+    n = w * h
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    core.resize(w, h)
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        screen = None
+        for f in range(3):
+            core.render(w, h, seed=90 + f, frames=f, max_bounces=3, path_keys_dev=C.c_void_p(keys.data_ptr()) if f == 0 else None)
+            ref = b.oracle.render(w, h, seed=90 + f, frames=f, max_bounces=3, screen=screen)
+            screen = ref["screen"]
+            if f == 0:
+                core.sync()
+                assert np.array_equal(keys.cpu().numpy().view(np.uint64), ref["path_key"].reshape(-1))
+        core.sync()
+        assert np.array_equal(core.read_framebuffer().view(np.uint32), screen.view(np.uint32))
+        tw, th = 64, 16
+        tx, ty = (w + tw - 1) // tw, (h + th - 1) // th
+        ids = np.random.default_rng(0).permutation(tx * ty).astype(np.uint32)
+        tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+        rays = torch.zeros(len(ids), dtype=torch.int32, device="cuda")
+        core.render(w, h, seed=90, frames=0, max_bounces=3, tile_ids=ids, tile_w=tw, tile_h=th,
+                    screen_dev=C.c_void_p(tiles.data_ptr()), tile_rays_dev=C.c_void_p(rays.data_ptr()))
+        core.sync()
+    finally:
+        core.use_own_stream()
+    ref = b.oracle.render(w, h, seed=90, frames=0, max_bounces=3)
+    c = ref["counters"]
+    assert int(rays.sum().item()) == c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for k, tid in enumerate(ids):
+        x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
+        ww, hh = min(tw, w - x0), min(th, h - y0)
+        assert np.array_equal(t[k, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))
