@@ -40,7 +40,9 @@ namespace math
 		ACR_HD vec3(float a, float b, float c) : x(a), y(b), z(c) {}
 		ACR_HD explicit vec3(float s) : x(s), y(s), z(s) {}
 		// two selects in sequence (not nested): hipcc turns this shape into v_cndmask, the nested one into branches
-		ACR_HD float operator[](int i) const { const float xy = i == 1 ? y : x; return i == 2 ? z : xy; }
+		// members are read before the selects: a select between two member loads can be turned into one load
+		// through a selected address, which pins the whole vector in memory
+		ACR_HD float operator[](int i) const { const float vx = x, vy = y, vz = z; const float xy = i == 1 ? vy : vx; return i == 2 ? vz : xy; }
 		ACR_HD void set(int i, float v) { if (i == 0) x = v; else if (i == 1) y = v; else z = v; }
 	};
 
