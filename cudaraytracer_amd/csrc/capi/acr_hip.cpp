@@ -61,6 +61,7 @@ struct acr_hip_ctx
 	// interval traversal (see acr_kernels.hip): usable for this scene, forced off by the caller, and the
 	// buffers through which its launches hand pixels to the six-plane list pass
 	bool intervalOk = false;
+	bool leafOrderOk = false; // near-side-first walks of mesh trees can break exact ties by item position
 	int traversalMode = ACR_TRAVERSAL_AUTO;
 	uint32_t *redoCount = nullptr; // device [2], used alternately by successive frames
 	uint32_t *redoList = nullptr;
@@ -144,10 +145,15 @@ namespace
 		return true;
 	}
 
+	// leavesAscend (optional): whether the non-empty item ranges of the leaves, taken in the order the
+	// reference's traversal visits them (left child first), ascend without overlap -- then the position of
+	// an item in the item array says which of two items the reference tests first.  sift() partitions the
+	// item array in place, left part first, so its trees always do.
 	bool checkBih(uint32_t depth, const uint32_t *start, const uint32_t *end, const uint8_t *flags, uint32_t itemCount, std::string &why,
-	              uint32_t *levelsUsed)
+	              uint32_t *levelsUsed, bool *leavesAscend = nullptr)
 	{
-		uint32_t deepest = 0;
+		uint32_t deepest = 0, lastEnd = 0;
+		if (leavesAscend) *leavesAscend = true;
 		if (depth < 1 || depth > ACR_MAX_BIH_DEPTH) { why = "BIH depth out of range"; return false; }
 		const uint64_t count = (1ull << depth) - 1;
 		std::vector<uint32_t> todo(1, 0u);
@@ -159,6 +165,10 @@ namespace
 			if (level > deepest) deepest = level;
 			if (flags[i] & ACR_NODE_LEAF) {
 				if (start[i] <= end[i] && end[i] > itemCount) { why = "leaf item range outside the item array"; return false; }
+				if (leavesAscend && start[i] < end[i]) {
+					if (start[i] < lastEnd) *leavesAscend = false;
+					lastEnd = end[i];
+				}
 				continue;
 			}
 			if ((flags[i] & ACR_NODE_AXIS_MASK) > 2) { why = "node axis > 2"; return false; }
@@ -357,6 +367,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	uint32_t maxMeshDepth = 1;
 	std::vector<uint32_t> meshLevels(s->num_meshes, 1), meshNodeAt(s->num_meshes, 0);
 	uint32_t packedMeshNodes = 0;
+	bool leafOrderOk = true; // item position == the reference's test order, in every mesh tree
 	for (uint32_t m = 0; m < s->num_meshes; m++) {
 		const uint32_t d = s->mesh_depth[m];
 		if (d < 1 || d > ACR_MAX_BIH_DEPTH) return fail(ctx, ACR_ERR_UNSUPPORTED, "mesh %u: BIH depth %u", m, d);
@@ -365,8 +376,10 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 		const uint32_t nb = s->mesh_node_begin[m];
 		const uint32_t triBegin = s->mesh_tri_begin[m];
 		if (triBegin > s->num_triangles) return fail(ctx, ACR_ERR_INVALID, "mesh %u: tri_begin out of range", m);
-		if (!checkBih(d, s->mnode_start + nb, s->mnode_end + nb, s->mnode_flags + nb, s->num_triangles - triBegin, why, &meshLevels[m]))
+		bool ascend = true;
+		if (!checkBih(d, s->mnode_start + nb, s->mnode_end + nb, s->mnode_flags + nb, s->num_triangles - triBegin, why, &meshLevels[m], &ascend))
 			return fail(ctx, ACR_ERR_INVALID, "mesh %u BIH: %s", m, why.c_str());
+		leafOrderOk = leafOrderOk && ascend;
 		if (s->mesh_material[m] >= s->num_materials) return fail(ctx, ACR_ERR_INVALID, "mesh %u: material index out of range", m);
 		if (meshLevels[m] > maxMeshDepth) maxMeshDepth = meshLevels[m];
 		meshNodeAt[m] = packedMeshNodes;
@@ -510,6 +523,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	ACR_HIP_TRY(ctx, hipMemcpy(ctx->blob, blob.data(), ctx->blobBytes, hipMemcpyHostToDevice));
 	ctx->header = h;
 	ctx->intervalOk = intervalOk;
+	ctx->leafOrderOk = leafOrderOk;
 	ctx->sceneDepthGiven = s->scene_depth;
 	ctx->haveScene = true;
 	return ACR_OK;
@@ -640,7 +654,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
-	const bool fast = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO;
+	// the interval form walks mesh trees that are not LDS-resident near side first, which needs leafOrderOk
+	const bool fast = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	if (fast && plan.meshGlobLevels) {
 		const size_t slots = size_t(grid) * kBlock;
 		if (slots >= (1ull << 32)) return fail(ctx, ACR_ERR_UNSUPPORTED, "launch too large for a mesh tree this deep");
@@ -685,6 +700,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	ctx->stats.scene_in_lds = uint32_t(plan.ldsMode);
 	ctx->stats.grid_blocks = grid;
 	ctx->stats.interval_traversal = fast ? 1u : 0u;
+	ctx->stats.near_first = (fast && plan.ldsMode != 2) ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }
@@ -722,7 +738,7 @@ int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const
 		p.hit = dHit; p.t = dT; p.prim = dPrim; p.position = dPos; p.normal = dNrm;
 		const LaunchPlan plan = planLds(ctx->header, 0, false);
 		p.lds_stack_slot = plan.stackSlot;
-		e = acr_dev_launch_trace(&p, plan.ldsMode, (ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO) ? 1 : 0, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
+		e = acr_dev_launch_trace(&p, plan.ldsMode, (ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && (plan.ldsMode == 2 || ctx->leafOrderOk)) ? 1 : 0, (n + kBlock - 1) / kBlock, plan.ldsBytes, ctx->stream);
 	}
 	if (e == hipSuccess && hit) e = hipMemcpyAsync(hit, dHit, n, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess && t) e = hipMemcpyAsync(t, dT, size_t(n) * 4, hipMemcpyDeviceToHost, ctx->stream);

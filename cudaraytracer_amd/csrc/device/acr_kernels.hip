@@ -64,11 +64,13 @@ extern __shared__ uint4 g_lds[];
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
 // Scene memory view.  SMALL/LARGE say whether that part of the blob was
-// staged into LDS at the same slot offsets.
-template <bool SMALL_LDS, bool LARGE_LDS>
+// staged into LDS at the same slot offsets.  NEAR_FIRST: the interval form walks mesh trees near side first
+// (see bihTraverseNear); the default is to do so exactly when the trees live in HBM, i.e. when they are deep.
+template <bool SMALL_LDS, bool LARGE_LDS, bool NEAR_FIRST = !LARGE_LDS>
 struct SceneMem
 {
 	static constexpr bool kLargeInLds = LARGE_LDS;
+	static constexpr bool kNearFirst = NEAR_FIRST;
 	const uint4 *__restrict__ g;
 	__device__ __forceinline__ uint4 small(uint32_t slot) const
 	{
@@ -382,6 +384,91 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 	}
 }
 
+// Near-side-first traversal, for the deep trees of scenes that live in HBM.
+//
+// bih.h:253-264 always walks the left child first, whatever the ray's direction; a deep tree then spends most of
+// its node visits and item tests behind the hit it ends up returning.  Visiting the child on the ray's near side
+// first, and dropping a waiting child once the current hit distance lies in front of it, ends with the nearest
+// hit W of the tree.  The reference's order ends with W too unless it drops a box b on the way to W's leaf:
+// that takes an earlier-found hit X with tmin(b) >= t_X (the drop, geometry.h:75) and t_X > t_W (else W would
+// not be the nearest), hence tmin(b) > t_W -- the box would have to start behind a hit it contains, which only
+// rounding can produce.  tmin never decreases along a path, so tmin(W's leaf) >= tmin(b), and these are the
+// same fp32 values here and there.  So: if no other hit X has t_W < t_X <= tmin(W's leaf), both orders
+// return W.  The
+// traversal reports the nearest hit that lost (`second`) and W's leaf tmin; the caller hands the pixel to the
+// reference-order pass when second <= tmin(W's leaf), which takes a double coincidence within rounding.  An
+// exact tie (common: an ulp of t is ~1e-6 of the scene) needs no such pass: the reference gives it to the hit it
+// finds first, and that is the one with the lower item number.
+// For X to be seen at all, boxes are only dropped when they start more than kNearPruneSlack behind the current
+// hit (far above the rounding that can put a box's tmin behind a hit inside it).
+constexpr float kNearPruneSlack = 1.0f + 1.0f / 32768.0f;
+
+// Resume at the deepest waiting child that can still hold a hit as near as `tc`; the waiting child is the
+// sibling of the child this path took on that level.
+__device__ __forceinline__ bool popNear(const LevelColumn &stack, uint32_t &pending, uint32_t &idx, uint32_t &level, float &tminB, float &tmaxB, float tc)
+{
+	while (pending != 0) {
+		const uint32_t l = 31u - uint32_t(__clz(int(pending)));
+		pending &= ~(1u << l);
+		const float2 b = stack.load(l);
+		if (b.x < tc) {
+			tminB = b.x;
+			tmaxB = b.y;
+			idx = (((idx + 1) >> (level - l - 1)) ^ 1u) - 1u;
+			level = l + 1;
+			return true;
+		}
+	}
+	return false;
+}
+
+// bihTraverseFast visiting the child on the ray's near side first; `tcur` returns the slackened hit distance and
+// `leaf` also gets the leaf box's tmin.
+template <bool KEYS = false, class LoadNode, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, const SlabArgs &sa, Interval box, const LevelColumn &stack, Leaf leaf, TCur tcur,
+                                                PathRec *path = nullptr)
+{
+	uint32_t idx = 0, level = 0, pending = 0;
+	float tminB = box.tmin, tmaxB = box.tmax;
+	for (;;) {
+		uint4 n = loadNode(idx);
+		bool alive = true;
+		while ((n.w & kNodeLeafBit) == 0) {
+			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
+			const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
+			const bool sg = ia < 0;
+			const float tl = (asF(n.x) - oa) * ia;
+			const float tr = (asF(n.y) - oa) * ia;
+			const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
+			const float nearSideMax = tCutFar < tmaxB ? tCutFar : tmaxB;
+			const float farSideMin = tCutNear > tminB ? tCutNear : tminB;
+			const float tc = tcur();
+			const bool hitNearSide = intervalHit(tminB, nearSideMax, tc);
+			const bool hitFarSide = intervalHit(farSideMin, tmaxB, tc);
+			if (hitNearSide || hitFarSide) {
+				if (hitNearSide && hitFarSide) {
+					pending |= 1u << level;
+					stack.store(level, make_float2(farSideMin, tmaxB));
+				}
+				if (hitNearSide) tmaxB = nearSideMax;
+				else tminB = farSideMin;
+				idx = 2 * idx + ((hitNearSide != sg) ? 1 : 2); // the near-side child is the left one for a positive direction
+				level++;
+			} else if (!popNear(stack, pending, idx, level, tminB, tmaxB, tc)) {
+				alive = false;
+				break;
+			}
+			n = loadNode(idx);
+		}
+		if (!alive)
+			return;
+		if (leaf(n.z, n.w & kNodeEndMask, tminB))
+			return;
+		if (!popNear(stack, pending, idx, level, tminB, tmaxB, tcur()))
+			return;
+	}
+}
+
 // HitInfo (geometry.h:22-27) for the world-space query, plus the primitive id
 struct WorldHit
 {
@@ -432,16 +519,24 @@ struct Columns
 	uint32_t meshGlobLevels, meshGlobStride;
 };
 
+// what a near-side-first traversal needs to know whether the visiting order could have mattered
+struct OrderCheck
+{
+	float second;   // distance of the nearest hit that lost against the current one
+	float leafTmin; // tmin of the leaf box the current hit was found in
+};
+
 // Face::intersect (geometry.h:123-146) for the items [start, end) of a leaf
-template <class Mem>
+template <bool NEAR = false, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
-                                              struct LocalHit &tmp, bool &intersected);
+                                              struct LocalHit &tmp, bool &intersected, OrderCheck *order = nullptr, float leafTmin = 0.0f);
 
 // Mesh::intersect (geometry.cu:52-61) for a local-space ray
 template <bool FAST, class Mem>
 __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, uint32_t meshId, const Ray &lr,
-                                              const SlabArgs &sa, LocalHit &tmp, const Columns &col)
+                                              const SlabArgs &sa, LocalHit &tmp, const Columns &col, bool &bail)
 {
+	constexpr bool NEAR = FAST && Mem::kNearFirst;
 	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
 	const uint4 q0 = mem.small(ms), q1 = mem.small(ms + 1), q2 = mem.small(ms + 2);
 	const vec3 bmin(asF(q0.x), asF(q0.y), asF(q0.z)), bmax(asF(q1.x), asF(q1.y), asF(q1.z));
@@ -460,7 +555,19 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 		if (!intervalHit(root.tmin, root.tmax, tmp.t))
 			return false;
 		const LevelColumn lc = {reinterpret_cast<float2 *>(col.mesh), col.meshGlob, col.meshGlobLevels, col.meshGlobStride};
-		bihTraverseFast(loadNode, sa, root, lc, leaf, tcur);
+		if constexpr (NEAR) {
+			OrderCheck order = {FLT_MAX, 0.0f};
+			auto leafNear = [&](uint32_t start, uint32_t end, float leafTmin) {
+				leafTriangles<true>(mem, triBase, q2.x, start, end, lr, tmp, intersected, &order, leafTmin);
+				return false;
+			};
+			auto tslack = [&]() { return tmp.t * kNearPruneSlack; };
+			bihTraverseNear(loadNode, sa, root, lc, leafNear, tslack);
+			// order.second == FLT_MAX: nothing lost in this mesh, and the hit (if any) replaced no earlier mesh's
+			if (order.second < FLT_MAX && order.second <= order.leafTmin) bail = true;
+		} else {
+			bihTraverseFast(loadNode, sa, root, lc, leaf, tcur);
+		}
 	} else {
 		SlabBox root;
 		root.init(sa, bmin, bmax);
@@ -475,9 +582,9 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 	return false;
 }
 
-template <class Mem>
+template <bool NEAR, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
-                                              LocalHit &tmp, bool &intersected)
+                                              LocalHit &tmp, bool &intersected, OrderCheck *order, float leafTmin)
 {
 	for (uint32_t i = start; i < end; i++) {
 		const uint32_t ts = triBase + i * kTriSlots;
@@ -487,11 +594,23 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 		const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
 		vec3 b;
 		float t;
-		if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t) && t < tmp.t) {
-			tmp.t = t;
-			tmp.bary = b;
-			tmp.tri = i + triFirst;
-			intersected = true;
+		if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t)) {
+			bool take = t < tmp.t;
+			if constexpr (NEAR) {
+				// An exact tie goes to the hit the reference finds first: items are numbered in the reference's
+				// visiting order (checked at upload), and a tie with an earlier mesh's hit stays with that mesh.
+				const bool tie = t == tmp.t;
+				if (take) order->second = tmp.t;
+				else if (!tie && t < order->second) order->second = t;
+				take = take || (tie && intersected && i + triFirst < tmp.tri);
+				if (take) order->leafTmin = leafTmin;
+			}
+			if (take) {
+				tmp.t = t;
+				tmp.bary = b;
+				tmp.tri = i + triFirst;
+				intersected = true;
+			}
 		}
 	}
 }
@@ -567,7 +686,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		const uint4 ids = mem.small(idSlot);
 		const uint32_t sel = (meshBegin + k) & 3u;
 		const uint32_t meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
-		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, col);
+		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, col, bail);
 	}
 
 	if (intersected) {
@@ -1041,11 +1160,13 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 template <bool SMALL_LDS, bool LARGE_LDS, bool KEYS>
 __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 {
+	// scenes walked near side first list pixels for two reasons; the others only for non-finite rays
+	constexpr bool ORDERED_FIRST = SceneMem<SMALL_LDS, LARGE_LDS>::kNearFirst;
 	const uint32_t count = *p.redo_count;
 	if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_count_next = 0;
 	if (count == 0) return;
 	const SceneHeader &sc = p.scene;
-	SceneMem<SMALL_LDS, LARGE_LDS> mem;
+	SceneMem<SMALL_LDS, LARGE_LDS, false> mem; // always the reference's visiting order here
 	mem.g = p.blob;
 	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
 	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
@@ -1060,8 +1181,16 @@ __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 		if (k < count) {
 			const uint32_t slot = p.redo_list[k];
 			vblock = slot / kBlock;
+			// a pixel listed because the visiting order could matter qualifies for the interval form in the
+			// reference's order; one listed for its ray fails again and gets the six-plane form below
+			if constexpr (ORDERED_FIRST) res = renderSlot<true, KEYS>(p, mem, vblock, slot % kBlock);
+		}
+		if constexpr (ORDERED_FIRST) __syncthreads(); // the two forms lay their LDS columns out differently
+		if (k < count && (!ORDERED_FIRST || res.bail)) {
+			const uint32_t slot = p.redo_list[k];
 			res = renderSlot<false, KEYS>(p, mem, vblock, slot % kBlock);
 		}
+		if constexpr (ORDERED_FIRST) __syncthreads();
 		// lanes of one wave may belong to different tiles and blocks here: count per lane
 		if (res.active) {
 			if (p.num_tiles != 0 && p.tile_rays) atomicAdd(&p.tile_rays[res.tileNo], 1u + res.cnt.shadow + res.cnt.bounce);

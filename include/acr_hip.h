@@ -170,7 +170,8 @@ typedef struct acr_stats {
 	uint32_t scene_in_lds;         /* 2 whole scene staged in LDS, 1 only the small tables, 0 none */
 	uint32_t grid_blocks;
 	uint32_t interval_traversal;   /* 1 when the last launch used the interval form (ACR_TRAVERSAL_AUTO on a qualifying scene) */
-	uint32_t six_plane_pixels;     /* pixels of that launch which were handed to the six-plane pass (needs collect_stats) */
+	uint32_t six_plane_pixels;     /* pixels of that launch which were handed to the reference-order list pass (needs collect_stats) */
+	uint32_t near_first;           /* 1 when that launch walked the mesh trees near side first (interval form, trees resident in HBM) */
 } acr_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -707,6 +707,7 @@ typedef struct mesh {
 	bih_t faces;        face_t *face_items; uint32_t nfaces;
 	uint32_t materialIndex;
 	uint32_t prim_base;
+	int near_first;     /* not in the reference: see mesh_bih_intersect_near */
 } mesh_t;
 
 static bbox_t face_bbox_cb(const void *item, const void *data) { return face_bbox((const face_t *)item, (const vertex_t *)data); }
@@ -773,6 +774,143 @@ static int face_item_intersect(const void *items, uint32_t i, const ray_t *r, hi
 	return face_intersect(&((const face_t *)items)[i], r, info, fc->vertices, fc->prim_base, st);
 }
 
+
+/* ---- NOT in the reference: the same tree walked near side first ----------
+ * The GPU path walks deep mesh trees visiting the child on the ray's near side first and dropping boxes that
+ * start behind the current hit.  This restates that order on the CPU for two purposes: counting the node
+ * visits and triangle tests of that order (the work the GPU path's roofline is priced on), and checking on the
+ * CPU that it returns what bih_tree_intersect returns.  The rules are the GPU path's:
+ *   - a box is kept while its tmin lies below the current hit distance times ORC_NEAR_SLACK;
+ *   - an exact tie goes to the item with the lower position in the item array (the one bih_tree_intersect finds
+ *     first), but never against a hit of an earlier mesh of the same object;
+ *   - if another hit X has t_W < t_X <= tmin(leaf of the winner W), the order could have mattered (the
+ *     reference may have dropped W's leaf): the mesh is walked again in the reference's order and counted in
+ *     order_doubts. */
+#define ORC_NEAR_SLACK (1.0f + 1.0f / 32768.0f)
+
+/* geometry.h:44-76 with the entry distance returned */
+static int bbox_intersect_tmin(const bbox_t *bb, const ray_t *r, float info_t, const bbargs_t *args, stats_t *st, float *tmin_out)
+{
+	const v3 *bounds = bb->bounds;
+	float tmin, tmax, tymin, tymax, tzmin, tzmax;
+	st->c.slab_tests++;
+	tmin = (bounds[args->sign[0]].x - r->o.x) * args->invD.x;
+	tmax = (bounds[1 - args->sign[0]].x - r->o.x) * args->invD.x;
+	tymin = (bounds[args->sign[1]].y - r->o.y) * args->invD.y;
+	tymax = (bounds[1 - args->sign[1]].y - r->o.y) * args->invD.y;
+	if ((tmin > tymax) || (tymin > tmax))
+		return 0;
+	if (tymin > tmin)
+		tmin = tymin;
+	if (tymax < tmax)
+		tmax = tymax;
+	tzmin = (bounds[args->sign[2]].z - r->o.z) * args->invD.z;
+	tzmax = (bounds[1 - args->sign[2]].z - r->o.z) * args->invD.z;
+	if ((tmin > tzmax) || (tzmin > tmax))
+		return 0;
+	if (tzmin > tmin)
+		tmin = tzmin;
+	if (tzmax < tmax)
+		tmax = tzmax;
+	*tmin_out = tmin;
+	return tmin < info_t && tmax > ACR_EPS;
+}
+
+static int mesh_bih_intersect_near(const mesh_t *m, const ray_t *r, hitinfo_t *info, stats_t *st)
+{
+	const bih_t *bih = &m->faces;
+	const node_t *tree = bih->tree;
+	const hitinfo_t entry = *info;
+	int intersected = 0;
+	int treeIdx[ORC_MAX_STACK];
+	bbox_t treeBB[ORC_MAX_STACK];
+	float treeTmin[ORC_MAX_STACK];
+	int depth = 0;
+	bbargs_t bbArgs;
+	float second = FLT_MAX, leafTmin = 0.0f;
+	uint32_t bestItem = 0;
+
+	bbargs_make(&bbArgs, r);
+	treeIdx[0] = 0;
+	treeBB[0] = bih->boundingBox;
+	if (!bbox_intersect_tmin(&treeBB[0], r, info->t * ORC_NEAR_SLACK, &bbArgs, st, &treeTmin[0]))
+		return 0; /* cannot happen after Mesh::intersect's own test of the same box */
+
+	while (depth >= 0) {
+		const int i = treeIdx[depth];
+		const bbox_t bb = treeBB[depth];
+		const float tminB = treeTmin[depth];
+		const node_t *n = &tree[i];
+		depth--;
+		if (!(tminB < info->t * ORC_NEAR_SLACK))
+			continue; /* a waiting box that now starts behind the hit */
+		if (!n->isLeaf) {
+			bbox_t cBB[2];
+			float cT[2];
+			int hit[2], nearSide, farSide;
+			st->c.node_visits++;
+			cBB[0] = bb;
+			cBB[1] = bb;
+			v3set(&cBB[0].bounds[1], n->axis, n->left);
+			v3set(&cBB[1].bounds[0], n->axis, n->right);
+			hit[0] = bbox_intersect_tmin(&cBB[0], r, info->t * ORC_NEAR_SLACK, &bbArgs, st, &cT[0]);
+			hit[1] = bbox_intersect_tmin(&cBB[1], r, info->t * ORC_NEAR_SLACK, &bbArgs, st, &cT[1]);
+			nearSide = bbArgs.sign[n->axis] ? 1 : 0; /* the left child is the near one for a positive direction */
+			farSide = 1 - nearSide;
+			if (hit[farSide]) {
+				depth++;
+				treeIdx[depth] = 2 * i + 1 + farSide;
+				treeBB[depth] = cBB[farSide];
+				treeTmin[depth] = cT[farSide];
+			}
+			if (hit[nearSide]) {
+				depth++;
+				treeIdx[depth] = 2 * i + 1 + nearSide;
+				treeBB[depth] = cBB[nearSide];
+				treeTmin[depth] = cT[nearSide];
+			}
+		} else {
+			uint32_t k;
+			for (k = n->start; k < n->end; k++) {
+				const face_t *f = &m->face_items[k];
+				const vertex_t *v0 = &m->vertices[f->indices[0]];
+				const vertex_t *v1 = &m->vertices[f->indices[1]];
+				const vertex_t *v2 = &m->vertices[f->indices[2]];
+				v3 b;
+				float t;
+				int take, tie;
+				st->c.triangle_tests++;
+				if (!my_intersect_ray_triangle(r->o, r->d, v0->position, v1->position, v2->position, &b, &t))
+					continue;
+				take = t < info->t;
+				tie = t == info->t;
+				if (take) second = info->t;
+				else if (!tie && t < second) second = t;
+				take = take || (tie && intersected && k < bestItem);
+				if (take) {
+					leafTmin = tminB;
+					bestItem = k;
+					info->t = t;
+					info->point.position = add3(r->o, scale3(r->d, t));
+					info->point.normal = add3(add3(lscale3(b.x, v0->normal), lscale3(b.y, v1->normal)), lscale3(b.z, v2->normal));
+					info->point.color = add3(add3(lscale3(b.x, v0->color), lscale3(b.y, v1->color)), lscale3(b.z, v2->color));
+					info->prim = m->prim_base + f->orig;
+					intersected = 1;
+				}
+			}
+		}
+	}
+	if (second < FLT_MAX && second <= leafTmin) {
+		face_ctx_t fc;
+		st->c.order_doubts++;
+		*info = entry;
+		fc.vertices = m->vertices;
+		fc.prim_base = m->prim_base;
+		return bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st, 0);
+	}
+	return intersected;
+}
+
 /* geometry.cu:52-61 */
 static int mesh_intersect(const mesh_t *m, const ray_t *r, hitinfo_t *info, stats_t *st)
 {
@@ -784,7 +922,8 @@ static int mesh_intersect(const mesh_t *m, const ray_t *r, hitinfo_t *info, stat
 	fc.prim_base = m->prim_base;
 	if (bbox_intersect_args(&m->boundingBox, r, info->t, &args, st)
 	    && (st->c.mesh_box_hits++, 1)
-	    && bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st, 0)) {
+	    && (m->near_first ? mesh_bih_intersect_near(m, r, info, st)
+	                      : bih_tree_intersect(&m->faces, m->face_items, face_item_intersect, r, info, &fc, st, 0))) {
 		info->materialIndex = m->materialIndex;
 		return 1;
 	}
@@ -1354,6 +1493,7 @@ static void counters_add(orc_counters *a, const orc_counters *b)
 	a->primary_hits += b->primary_hits; a->node_visits += b->node_visits; a->slab_tests += b->slab_tests;
 	a->object_visits += b->object_visits; a->mesh_visits += b->mesh_visits; a->triangle_tests += b->triangle_tests;
 	a->object_hits += b->object_hits; a->mesh_box_hits += b->mesh_box_hits;
+	a->order_doubts += b->order_doubts;
 }
 
 int orc_render(const orc_scene *s, const orc_camera *cam_in, const orc_frame *f,
@@ -1417,6 +1557,11 @@ void orc_trace_rays(const orc_scene *s, uint32_t n, const float *origins, const 
 /* inspection + unit entry points                                            */
 /* ======================================================================== */
 
+void orc_scene_set_mesh_order(orc_scene *s, int near_first)
+{
+	uint32_t i;
+	for (i = 0; i < s->nmeshes; i++) s->meshes[i].near_first = near_first != 0;
+}
 void orc_scene_camera(const orc_scene *s, orc_camera *out) { *out = s->camera; }
 uint32_t orc_scene_num_objects(const orc_scene *s) { return s->nobjects; }
 uint32_t orc_scene_num_meshes(const orc_scene *s) { return s->nmeshes; }

@@ -103,6 +103,7 @@ typedef struct orc_counters {
 	uint64_t triangle_tests;  /* Face::intersect calls */
 	uint64_t object_hits;     /* Object::intersect calls whose local ray hit something (scene.cu:426-437 runs) */
 	uint64_t mesh_box_hits;   /* Mesh::intersect calls that passed the mesh box test (geometry.cu:55) */
+	uint64_t order_doubts;    /* near-side-first order only: mesh traversals redone in the reference's order */
 } orc_counters;
 
 typedef struct orc_frame {
@@ -148,6 +149,11 @@ void orc_scene_light(const orc_scene *s, uint32_t i, int32_t *type, float out[14
  * read when frames>0.  pixel_map may be NULL (identity).  Returns 0 on success. */
 int orc_render(const orc_scene *s, const orc_camera *cam, const orc_frame *f,
                float *screen, const int32_t *pixel_map, const orc_aov *aov, orc_counters *counters);
+
+/* NOT in the reference.  near_first != 0: mesh trees are walked near side first, as the GPU path walks deep
+ * trees; results must not change (that is what the tests check), the node / slab / triangle counters become those
+ * of that order.  Default 0: the reference's order (bih.h:253-264). */
+void orc_scene_set_mesh_order(orc_scene *s, int near_first);
 
 /* Closest-hit query for arbitrary rays (Scene::intersect, scene.cu:204). tmax preset per ray. */
 void orc_trace_rays(const orc_scene *s, uint32_t n, const float *origins, const float *dirs,

@@ -126,3 +126,28 @@ def random_instanced_scene(acr, seed, n_objects=40):
     d.nodes.append(dict(name="Cam", parent=0, transform=trs([0.0, 0.0, 11.0], np.array([0, 0, 1.0]), 0.0, [1, 1, 1]), meshes=[]))
     d.camera = dict(name="Cam", aspect=0.0, hfov=0.7853982, position=[0, 0, 0], up=[0, 1, 0], look_at=[0, 0, -1])
     return d
+
+
+def duplicate_triangle_scene(acr, n, seed=5, spread=0.3):
+    """n random triangles, each present twice (the copies in reverse order) in ONE mesh: every hit is an exact tie
+    between two items of the mesh tree, usually in different leaves.  One point light and the camera at (0, 0, 5)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    data = acr.ImportData()
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    tri = (c + rng.uniform(-spread, spread, (n, 3, 3))).astype(np.float32)
+    tri = np.concatenate([tri, tri[::-1]], axis=0)
+    p = tri.reshape(-1, 3)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(p), 1))
+    data.meshes.append(dict(positions=p, normals=nrm, indices=np.arange(len(p), dtype=np.uint32).reshape(-1, 3), material=0))
+    data.materials = [dict(diffuse=[0.8, 0.8, 0.8], ambient=[0, 0, 0], specular=[0, 0, 0], refracti=0.0)]
+    ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    at5 = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 5, 1]  # column-major translation to (0, 0, 5)
+    data.nodes = [dict(name="<Root>", parent=-1, transform=ident, meshes=[]),
+                  dict(name="Obj", parent=0, transform=ident, meshes=[0]),
+                  dict(name="L0", parent=0, transform=at5, meshes=[]),
+                  dict(name="Cam", parent=0, transform=at5, meshes=[])]
+    data.lights = [dict(name="L0", type=0, position=[0, 0, 0], direction=[0, 0, -1], ambient=[3, 3, 3], diffuse=[3, 3, 3],
+                        specular=[3, 3, 3], att=[0, 1, 0], cones=[6.28, 6.28])]
+    data.camera = dict(name="Cam", aspect=0.0, hfov=0.6, position=[0, 0, 0], up=[0, 1, 0], look_at=[0, 0, -1])
+    return data

@@ -26,7 +26,8 @@ class OrcNode(C.Structure):
 
 class OrcCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_bounce", "primary_hits", "node_visits",
-                                          "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits", "mesh_box_hits")]
+                                          "slab_tests", "object_visits", "mesh_visits", "triangle_tests", "object_hits", "mesh_box_hits",
+                                          "order_doubts")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -64,6 +65,8 @@ def lib():
         L.orc_mesh_bih.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(OrcNode), c_u32_p]
         L.orc_mesh_info.argtypes = [C.c_void_p, C.c_uint32, c_float_p, c_float_p, c_float_p, c_u32_p, c_u32_p]
         L.orc_scene_light.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), c_float_p]
+        L.orc_scene_set_mesh_order.restype = None
+        L.orc_scene_set_mesh_order.argtypes = [C.c_void_p, C.c_int]
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.POINTER(OrcFrame), c_float_p, C.POINTER(C.c_int32),
                                  C.POINTER(OrcAov), C.POINTER(OrcCounters)]
@@ -99,6 +102,10 @@ class OracleScene:
             raise RuntimeError("orc_scene_create failed")
         self.camera = OrcCamera()
         self.L.orc_scene_camera(self.h, C.byref(self.camera))
+
+    def set_mesh_order(self, near_first):
+        """near_first: mesh trees are walked near side first (NOT the reference's order; results must not change)."""
+        self.L.orc_scene_set_mesh_order(self.h, 1 if near_first else 0)
 
     def close(self):
         if self.h:

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import Built, random_instanced_scene, soup_data
+from conftest import Built, duplicate_triangle_scene, random_instanced_scene, soup_data
 
 pytestmark = pytest.mark.gpu
 
@@ -544,3 +544,48 @@ def test_random_instanced_scene_modes(core, acr, orc):
         x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
         ww, hh = min(tw, w - x0), min(th, h - y0)
         assert np.array_equal(t[k, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))
+
+
+@pytest.mark.parametrize("ntri,depth,extent,edge", [(60000, 14, 1.0, 0.1), (400000, 17, 3.0, 0.15)])
+def test_near_side_first_mesh_order(core, acr, orc, ntri, depth, extent, edge):
+    """Trees that are not LDS-resident are walked near side first; frames and raw ray queries equal the oracle's
+    (which walks them in the reference's order) and the six-plane kernel's, and no pixel needed the
+    reference-order pass."""
+    b = Built(acr, orc, soup_data(acr, ntri, seed=9, edge=edge, extent=extent), mesh_depth=depth)
+    load(core, b)
+    w, h = 256, 144
+    ref = b.oracle.render(w, h, seed=21, frames=0, max_bounces=3)
+    img, pid, ht, st = render(core, w, h, seed=21, frames=0, max_bounces=3)
+    assert st.near_first == 1 and st.interval_traversal == 1 and st.scene_in_lds != 2
+    assert_same(img, pid, ht, st, ref)
+    assert (pid != 0xFFFFFFFF).mean() > 0.1
+    core.set_traversal(six_plane_only=True)
+    try:
+        img6, pid6, ht6, st6 = render(core, w, h, seed=21, frames=0, max_bounces=3)
+    finally:
+        core.set_traversal(six_plane_only=False)
+    assert st6.near_first == 0 and st6.interval_traversal == 0
+    assert np.array_equal(img6.view(np.uint32), img.view(np.uint32)) and np.array_equal(pid6, pid)
+    rng = np.random.default_rng(3)
+    n = 20000
+    org = rng.uniform(-1.5 * extent, 1.5 * extent, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    g, r = core.trace_rays(org, d), b.oracle.trace_rays(org, d)
+    assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"])
+    assert np.array_equal(g["t"].view(np.uint32), r["t"].view(np.uint32))
+    assert r["hit"].sum() > n // 20
+
+
+def test_near_side_first_exact_ties(core, acr, orc):
+    """Every hit is an exact tie between two copies of a triangle (30 000 triangles, each twice, depth-14 tree
+    in HBM): the copy the reference tests first must win, whatever the visiting order."""
+    b = Built(acr, orc, duplicate_triangle_scene(acr, 30000, spread=0.05), mesh_depth=14)
+    load(core, b)
+    w, h = 256, 256
+    ref = b.oracle.render(w, h, seed=4, frames=0, max_bounces=2)
+    img, pid, ht, st = render(core, w, h, seed=4, frames=0, max_bounces=2)
+    assert st.near_first == 1
+    assert_same(img, pid, ht, st, ref)
+    assert (pid != 0xFFFFFFFF).mean() > 0.3
+    # the winners are spread over both halves of the item array: position in the tree's item order decides, not the copy
+    assert 0.2 < (pid[pid != 0xFFFFFFFF] < 30000).mean() < 0.8

@@ -54,8 +54,10 @@ def test_committed_counters_match(built):
         gold = json.load(f)
     g = gold["C1 triangles 640x480 primary+shadow"]
     c = built["triangles"].oracle.render(640, 480, seed=g["seed"], max_bounces=1, aov=False)["counters"]
-    for k, v in c.items():
-        assert g[k] == v, k
+    for k, v in g.items():
+        if k in c:
+            assert c[k] == v, k
+    assert c["order_doubts"] == 0  # the reference's order was used
 
 
 def test_primary_hits_agree_with_trace_rays_geometry(built):

@@ -116,7 +116,7 @@ def main():
     out = dict(tag=args.tag or (args.lib or "default"), scene=("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
                size=args.size, bounces=args.bounces, ms_mean=float(ms.mean()), ms_min=float(ms.min()), ms_median=float(np.median(ms)),
                rays=int(rays), grays_per_s=rays / (float(np.median(ms)) * 1e-3) / 1e9, digest=digest,
-               lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
+               six_plane_pixels=st.six_plane_pixels, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
     print(json.dumps(out), flush=True)
     core.close()
 
