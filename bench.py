@@ -182,7 +182,7 @@ def main():
             core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr, collect_stats=True)
             st = core.read_stats()
             rays += st.rays_primary + st.rays_shadow + st.rays_bounce
-        lds_bytes, lds_mode, interval = st.lds_bytes, st.scene_in_lds, st.interval_traversal
+        lds_bytes, lds_mode, interval, near_first = st.lds_bytes, st.scene_in_lds, st.interval_traversal, st.near_first
     else:
         def frame_args():
             if cameras:
@@ -324,8 +324,15 @@ def main():
                 out["cpu_baseline"] = {"value": cpu_rays / t_cpu / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                        "sample": sample, "value_1core": (c1["rays_primary"] + c1["rays_shadow"] + c1["rays_bounce"]) / t1 / 1e6,
                                        "host_cpus": os.cpu_count()}
-                # algorithmic work per ray from the oracle's counters of the sample
+                # algorithmic work per ray from the oracle's counters of the sample; when the kernel walks the mesh
+                # trees near side first, from the oracle walking them in that order over the same sample
                 rays0 = counters["rays_primary"] + counters["rays_shadow"] + counters["rays_bounce"]
+                if near_first:
+                    o.set_mesh_order(True)
+                    counters = o.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES, threads=threads, aov=False,
+                                        camera=cam0, row_begin=r0, row_end=r1)["counters"]
+                    o.set_mesh_order(False)
+                    roof["note"] += "; mesh trees walked near side first: work counters are the oracle's for that order"
                 fl = algorithmic_flops(counters, num_lights)
                 tf = fl / rays0 * (rays / args.steps) / (kernel_ms * 1e-3) / 1e12
                 out["roofline_valu"] = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

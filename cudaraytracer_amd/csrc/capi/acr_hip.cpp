@@ -85,7 +85,9 @@ struct acr_hip_ctx
 namespace
 {
 	constexpr uint32_t kBlock = ACR_BLOCK;
-	constexpr uint32_t kBlockRows = kBlock / 16; // a workgroup covers 16 x kBlockRows pixels of a full frame
+	constexpr uint32_t kSlots = ACR_BLOCK_SLOTS;
+	constexpr uint32_t kGroupsPerBlock = kSlots / kBlock; // workgroups per block of 16 x 16 pixel slots
+	constexpr uint32_t kBlockRows = kSlots / 16;
 	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
 	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
 	constexpr size_t kLdsBudget = 64 * 1024;
@@ -212,7 +214,7 @@ namespace
 		// six-plane traversal's undo column (the list pass runs in the same LDS block).  A deep mesh tree keeps
 		// only its deepest levels' waiting-child entries in LDS, so that the columns stay within what lets four
 		// workgroups share a CU (the kernel's register budget allows four); the levels above go to global memory.
-		constexpr size_t kColumnBudget = 30 * 1024;
+		constexpr size_t kColumnBudget = size_t(30) * 1024 * kBlock / 256;
 		uint32_t meshLdsLevels = h.max_mesh_depth;
 		const size_t perLevel = size_t(2) * kBlock * 4;
 		if (splitDeepColumns && (h.scene_depth + meshLdsLevels) * perLevel > kColumnBudget) {
@@ -589,7 +591,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		const uint32_t tilesY = (f->height + f->tile_h - 1) / f->tile_h;
 		for (uint32_t i = 0; i < f->num_tiles; i++)
 			if (f->tile_ids[i] >= tilesX * tilesY) return fail(ctx, ACR_ERR_INVALID, "tile_ids[%u] out of range", i);
-		const uint64_t g = uint64_t(f->num_tiles) * (f->tile_w / 16) * (f->tile_h / 16);
+		const uint64_t g = uint64_t(f->num_tiles) * (f->tile_w / 16) * (f->tile_h / 16) * kGroupsPerBlock;
 		if (g >= (1ull << 31)) return fail(ctx, ACR_ERR_INVALID, "too many tiles");
 		grid = uint32_t(g);
 		if (f->path_keys_dev) return fail(ctx, ACR_ERR_INVALID, "traversal-path keys need a full-frame launch");
@@ -599,7 +601,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		// than the 64 bits of the key, so only the primary ray's traversal reaches it, which is what the kernels record.
 		if (f->path_keys_dev && ctx->sceneDepthGiven < 6)
 			return fail(ctx, ACR_ERR_UNSUPPORTED, "traversal-path keys need a scene BIH of MAX_DEPTH >= 6 (got %u)", ctx->sceneDepthGiven);
-		grid = ((f->width + 15) / 16) * ((f->height + kBlockRows - 1) / kBlockRows);
+		grid = ((f->width + 15) / 16) * ((f->height + kBlockRows - 1) / kBlockRows) * kGroupsPerBlock;
 	}
 
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));

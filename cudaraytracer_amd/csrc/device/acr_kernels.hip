@@ -49,7 +49,9 @@ namespace acr
 namespace dev
 {
 
-constexpr int kBlock = ACR_BLOCK;
+constexpr int kBlock = ACR_BLOCK;          // work-items per workgroup
+constexpr uint32_t kSlots = ACR_BLOCK_SLOTS; // pixel slots per block of the launch grid: 16 x 16 pixels, kSlots / kBlock workgroups
+static_assert(ACR_BLOCK_SLOTS % ACR_BLOCK == 0 && ACR_BLOCK % 64 == 0, "a block of pixel slots is a whole number of workgroups of whole waves");
 // resident waves per SIMD the render kernel is compiled for (sets its VGPR budget: 512 / waves)
 #ifndef ACR_RENDER_WAVES
 #define ACR_RENDER_WAVES 4
@@ -586,9 +588,7 @@ template <bool NEAR, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
                                               LocalHit &tmp, bool &intersected, OrderCheck *order, float leafTmin)
 {
-	for (uint32_t i = start; i < end; i++) {
-		const uint32_t ts = triBase + i * kTriSlots;
-		const uint4 t0 = mem.large(ts), t1 = mem.large(ts + 1), t2 = mem.large(ts + 2);
+	auto test = [&](uint32_t i, const uint4 &t0, const uint4 &t1, const uint4 &t2) {
 		const vec3 a(asF(t0.x), asF(t0.y), asF(t0.z));
 		const vec3 e1(asF(t0.w), asF(t1.x), asF(t1.y));
 		const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
@@ -611,6 +611,23 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 				tmp.tri = i + triFirst;
 				intersected = true;
 			}
+		}
+	};
+	if constexpr (Mem::kLargeInLds) {
+		for (uint32_t i = start; i < end; i++) {
+			const uint32_t ts = triBase + i * kTriSlots;
+			test(i, mem.large(ts), mem.large(ts + 1), mem.large(ts + 2));
+		}
+	} else {
+		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so two records are fetched per
+		// trip (the second one again when the leaf holds an odd number) and tested in item order.
+		for (uint32_t i = start; i < end; i += 2) {
+			const uint32_t i1 = i + 1 < end ? i + 1 : i;
+			const uint32_t ts = triBase + i * kTriSlots, ts1 = triBase + i1 * kTriSlots;
+			const uint4 a0 = mem.large(ts), a1 = mem.large(ts + 1), a2 = mem.large(ts + 2);
+			const uint4 b0 = mem.large(ts1), b1 = mem.large(ts1 + 1), b2 = mem.large(ts1 + 2);
+			test(i, a0, a1, a2);
+			if (i1 != i) test(i1, b0, b1, b2);
 		}
 	}
 }
@@ -936,7 +953,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
 	} else {
 		oldx = (vblock % p.blocks_x) * 16u + lx;
-		oldy = (vblock / p.blocks_x) * uint32_t(kBlock / 16) + ly;
+		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
 		outSlot = 0;
 	}
 
@@ -1143,16 +1160,19 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 
 	const bool tiled = p.num_tiles != 0;
 	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
-	const SlotResult res = renderSlot<FAST, KEYS>(p, mem, blockIdx.x, threadIdx.x);
+	// this workgroup's part of its block of pixel slots
+	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
+	const uint32_t vblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
+	const SlotResult res = renderSlot<FAST, KEYS>(p, mem, vblock, vtid);
 	if constexpr (FAST) {
 		if (res.bail) {
 			const uint32_t at = atomicAdd(p.redo_count, 1u);
-			p.redo_list[at] = blockIdx.x * kBlock + threadIdx.x;
+			p.redo_list[at] = firstSlot + threadIdx.x;
 		}
 	}
 	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
 		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
-	reportCounts(p, res, blockIdx.x);
+	reportCounts(p, res, vblock);
 }
 
 // Renders the pixel slots listed by a FAST launch with the six-plane traversal: a fixed small grid that
@@ -1180,15 +1200,15 @@ __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 		uint32_t vblock = 0;
 		if (k < count) {
 			const uint32_t slot = p.redo_list[k];
-			vblock = slot / kBlock;
+			vblock = slot / kSlots;
 			// a pixel listed because the visiting order could matter qualifies for the interval form in the
 			// reference's order; one listed for its ray fails again and gets the six-plane form below
-			if constexpr (ORDERED_FIRST) res = renderSlot<true, KEYS>(p, mem, vblock, slot % kBlock);
+			if constexpr (ORDERED_FIRST) res = renderSlot<true, KEYS>(p, mem, vblock, slot % kSlots);
 		}
 		if constexpr (ORDERED_FIRST) __syncthreads(); // the two forms lay their LDS columns out differently
 		if (k < count && (!ORDERED_FIRST || res.bail)) {
 			const uint32_t slot = p.redo_list[k];
-			res = renderSlot<false, KEYS>(p, mem, vblock, slot % kBlock);
+			res = renderSlot<false, KEYS>(p, mem, vblock, slot % kSlots);
 		}
 		if constexpr (ORDERED_FIRST) __syncthreads();
 		// lanes of one wave may belong to different tiles and blocks here: count per lane

@@ -9,7 +9,9 @@
 
 #include "device_scene.h"
 
-// work-items per workgroup of the render kernels; a workgroup covers 16 x (ACR_BLOCK / 16) pixels
+// A render launch is a grid of blocks of ACR_BLOCK_SLOTS pixel slots (16 x 16 pixels, four 8 x 8 waves); a
+// block is rendered by ACR_BLOCK_SLOTS / ACR_BLOCK workgroups of ACR_BLOCK work-items.
+#define ACR_BLOCK_SLOTS 256
 #ifndef ACR_BLOCK
 #define ACR_BLOCK 256
 #endif
