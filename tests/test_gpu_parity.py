@@ -589,3 +589,41 @@ def test_near_side_first_exact_ties(core, acr, orc):
     assert (pid != 0xFFFFFFFF).mean() > 0.3
     # the winners are spread over both halves of the item array: position in the tree's item order decides, not the copy
     assert 0.2 < (pid[pid != 0xFFFFFFFF] < 30000).mean() < 0.8
+
+
+def test_trees_whose_leaves_do_not_ascend_get_the_six_plane_kernel(core, acr, orc):
+    """The near-side-first walk breaks exact ties by item position, which needs the leaves' item ranges to ascend in
+    left-first order.  A tree without that property (two sibling leaves' ranges swapped by hand) must be rendered by
+    the six-plane kernel, in the order as written."""
+    b = Built(acr, orc, soup_data(acr, 3000, seed=4, edge=0.08), mesh_depth=10)
+    s = b.scene.soa
+    n = (1 << int(s.mesh_depth[0])) - 1
+    nb = int(s.mesh_node_begin[0])
+    flags = np.ctypeslib.as_array(s.mnode_flags, (s.num_mesh_nodes,))[nb:nb + n]
+    start = np.ctypeslib.as_array(s.mnode_start, (s.num_mesh_nodes,))[nb:nb + n]
+    end = np.ctypeslib.as_array(s.mnode_end, (s.num_mesh_nodes,))[nb:nb + n]
+    load(core, b)
+    _, _, _, st = render(core, 64, 64, seed=1, frames=0, max_bounces=1)
+    assert st.near_first == 1
+    # two sibling leaves (children 2i+1, 2i+2 of a reachable internal node), both non-empty
+    pair = None
+    todo = [0]
+    while todo and pair is None:
+        i = todo.pop()
+        if flags[i] & 4:  # leaf
+            continue
+        l, r = 2 * i + 1, 2 * i + 2
+        if (flags[l] & 4) and (flags[r] & 4) and start[l] < end[l] and start[r] < end[r]:
+            pair = (l, r)
+        todo += [r, l]
+    assert pair is not None
+    l, r = pair
+    keep = (int(start[l]), int(end[l]), int(start[r]), int(end[r]))
+    try:
+        start[l], end[l], start[r], end[r] = keep[2], keep[3], keep[0], keep[1]
+        core.upload_scene(s)
+        img, pid, ht, st = render(core, 64, 64, seed=1, frames=0, max_bounces=1)
+        assert st.near_first == 0 and st.interval_traversal == 0
+    finally:
+        start[l], end[l], start[r], end[r] = keep
+        core.upload_scene(s)
