@@ -257,8 +257,9 @@ def main():
                        f"full-width bands of {TILE_H} rows over {world} GPUs, cost-balanced contiguous runs, received in place on rank 0 over RCCL, two frames in flight"},
         }
         if world == 1:
-            kernel = "renderKernel<%s,%s,%s>" % ("true" if lds_mode >= 1 else "false", "true" if lds_mode == 2 else "false",
-                                                 "true" if interval else "false")
+            tf_ = lambda v: "true" if v else "false"
+            kernel = "renderKernel<%s, %s, %s, false, %s>" % (tf_(lds_mode >= 1), tf_(lds_mode == 2), tf_(interval),
+                                                             tf_(interval and MAX_BOUNCES == 1))
             frame_bytes = BYTES_PER_PIXEL * WIDTH * HEIGHT
             roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": frame_bytes,

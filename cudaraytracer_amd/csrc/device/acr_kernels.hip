@@ -918,9 +918,12 @@ struct SlotResult
 // (vblock, vtid) name the slot: workgroup vblock of the frame's launch grid, work-item vtid in it.  The LDS
 // columns belong to the executing work-item (threadIdx.x), which need not be vtid.
 // KEYS: also records the pixel's traversal-path key (the reference's per-pixel Path, renderer.cu:341,372,380,386).
-template <bool FAST, bool KEYS, class Mem>
+// ONE: the launch has max_bounces == 1 (rayColor<1>: primary ray, shadow rays, no continuation), known at compile
+// time as MAX_BOUNCES is in the reference (renderer.cu:10), so that nothing of the bounce loop is carried.
+template <bool FAST, bool KEYS, bool ONE = false, class Mem>
 __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
+	const uint32_t maxBounces = ONE ? 1u : p.max_bounces;
 	const SceneHeader &sc = p.scene;
 	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
 	Columns col;
@@ -1002,7 +1005,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 	if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
 	if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
 	for (;;) {
-		if (level == p.max_bounces) // rayColor<0> (renderer.cu:318-324)
+		if (level == maxBounces) // rayColor<0> (renderer.cu:318-324)
 			break;
 		WorldHit info;
 		info.t = FLT_MAX;
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		Ray nr;
 		nr.o = info.position;
 		nr.d = vec3(0, 0, 0);
-		const bool last = level + 1 == p.max_bounces; // the next level returns (0,0,0,1) whatever the ray
+		const bool last = level + 1 == maxBounces; // the next level returns (0,0,0,1) whatever the ray
 		if (refractiveIndex == 0) {
 			const vec3 cd = source * diffuse;
 			const vec3 cs = source * specular;
@@ -1149,7 +1152,7 @@ __device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotRe
 
 // One work-item per pixel slot of the frame (or of the listed tiles).
 // FAST: interval traversal; pixels it cannot serve are appended to p.redo_list for renderListKernel.
-template <bool SMALL_LDS, bool LARGE_LDS, bool FAST, bool KEYS>
+template <bool SMALL_LDS, bool LARGE_LDS, bool FAST, bool KEYS, bool ONE = false>
 __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_RENDER_WAVES_HBM) renderKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
@@ -1163,7 +1166,7 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 	// this workgroup's part of its block of pixel slots
 	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
 	const uint32_t vblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
-	const SlotResult res = renderSlot<FAST, KEYS>(p, mem, vblock, vtid);
+	const SlotResult res = renderSlot<FAST, KEYS, ONE>(p, mem, vblock, vtid);
 	if constexpr (FAST) {
 		if (res.bail) {
 			const uint32_t at = atomicAdd(p.redo_count, 1u);
@@ -1319,6 +1322,10 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 		return launchWithLds(k, *p, grid, ldsBytes, stream);
 	}
 	K k = ldsMode == 2 ? renderKernel<true, true, true, KEYS> : (ldsMode == 1 ? renderKernel<true, false, true, KEYS> : renderKernel<false, false, true, KEYS>);
+	if constexpr (!KEYS) {
+		if (p->max_bounces == 1)
+			k = ldsMode == 2 ? renderKernel<true, true, true, false, true> : (ldsMode == 1 ? renderKernel<true, false, true, false, true> : renderKernel<false, false, true, false, true>);
+	}
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
 	K kl = ldsMode == 2 ? renderListKernel<true, true, KEYS> : (ldsMode == 1 ? renderListKernel<true, false, KEYS> : renderListKernel<false, false, KEYS>);
