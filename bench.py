@@ -194,6 +194,17 @@ def main():
         dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
                                    rebalance_every=1 if cameras else 16, stage_through_host=rehearsal)
+        # Shares of the frame from measured speed (untimed, before the warm-up): a rank that has to send its piece
+        # over one xGMI link finishes fewer bands per second than rank 0, which only renders.  Three times: the
+        # later calls fit each phase's fixed cost and cost per band through two measurements at different shares.
+        if os.environ.get("ACR_BENCH_EQUAL_SHARES") != "1":
+            dr.render_frame()
+            dr.finish()
+            for _ in range(3):
+                cal = dr.calibrate(frames=3)
+            if rank == 0 and cal:
+                print("[shares] render ms %s send ms %s shares %s" % ([round(1e3 * float(x), 3) for x in cal["render_s"]],
+                      [round(1e3 * float(x), 3) for x in cal["send_s"]], [round(float(x), 3) for x in cal["weights"]]), file=sys.stderr)
         for _ in range(args.warmup):
             dr.render_frame()
         barrier()
@@ -254,8 +265,10 @@ def main():
             "data": data_text,
             "config": {"workload": wl["text"], "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
                        "parallelism": "single GPU, full frame" if world == 1 else
-                       f"full-width bands of {TILE_H} rows over {world} GPUs, cost-balanced contiguous runs, received in place on rank 0 over RCCL, two frames in flight"},
+                       f"full-width bands of {TILE_H} rows over {world} GPUs, contiguous runs balanced by measured cost and by each rank's measured speed (render + send), received in place on rank 0 over RCCL, two frames in flight"},
         }
+        if world > 1 and dr.plan.weights is not None:
+            out["config"]["shares"] = [round(float(x), 4) for x in dr.plan.weights]
         if world == 1:
             tf_ = lambda v: "true" if v else "false"
             kernel = "renderKernel<%s, %s, %s, false, %s>" % (tf_(lds_mode >= 1), tf_(lds_mode == 2), tf_(interval),

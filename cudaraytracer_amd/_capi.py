@@ -158,6 +158,7 @@ HOST_SYMBOLS = {
     "acr_host_renderer_ctx": (C.c_void_p, [C.c_void_p]),
     "acr_host_renderer_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "acr_host_partition_tiles": (C.c_int, [c_u32_p, c_float_p, C.c_uint32, C.c_uint32, c_u32_p]),
+    "acr_host_partition_tiles_weighted": (C.c_int, [c_u32_p, c_float_p, C.c_uint32, C.c_uint32, c_float_p, c_u32_p]),
     "acr_host_tile_order": (C.c_int, [C.c_uint32, C.c_uint32, c_u32_p]),
     "acr_host_kat": (C.c_int, [C.c_char_p, c_float_p, c_float_p]),
     "acr_host_fastersin": (C.c_float, [C.c_float]),

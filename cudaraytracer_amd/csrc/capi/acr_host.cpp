@@ -317,21 +317,28 @@ int acr_host_renderer_save(acr_host_renderer *r, const char *path)
 	return guarded(r, [&] { r->renderer->save(path); });
 }
 
-// Contiguous runs along `order` with near-equal summed cost: part k ends at
-// the first tile where the running cost reaches (k+1)/parts of the total.
-int acr_host_partition_tiles(const uint32_t *order, const float *cost, uint32_t num_tiles, uint32_t parts, uint32_t *begin_out)
+// Contiguous runs along `order` whose summed costs are in the ratio of `weights` (equal when weights is null):
+// part k ends at the first tile where the running cost reaches the sum of the first k+1 weights' share of the total.
+int acr_host_partition_tiles_weighted(const uint32_t *order, const float *cost, uint32_t num_tiles, uint32_t parts, const float *weights,
+                                      uint32_t *begin_out)
 {
 	if (!order || !begin_out || parts == 0) return ACR_ERR_INVALID;
-	double total = 0;
+	double total = 0, wsum = 0;
 	for (uint32_t i = 0; i < num_tiles; i++) {
 		if (order[i] >= num_tiles) return ACR_ERR_INVALID;
 		total += cost ? double(cost[order[i]] > 0 ? cost[order[i]] : 0) : 1.0;
 	}
+	for (uint32_t k = 0; k < parts; k++) {
+		if (weights && !(weights[k] >= 0)) return ACR_ERR_INVALID; // negative or NaN
+		wsum += weights ? double(weights[k]) : 1.0;
+	}
+	if (!(wsum > 0)) return ACR_ERR_INVALID;
 	begin_out[0] = 0;
 	uint32_t at = 0;
-	double run = 0;
+	double run = 0, wrun = 0;
 	for (uint32_t k = 1; k < parts; k++) {
-		const double target = total * double(k) / double(parts);
+		wrun += weights ? double(weights[k - 1]) : 1.0;
+		const double target = total * wrun / wsum;
 		while (at < num_tiles) {
 			const double c = cost ? double(cost[order[at]] > 0 ? cost[order[at]] : 0) : 1.0;
 			// stop before the tile that would overshoot the target by more than it undershoots
@@ -343,6 +350,11 @@ int acr_host_partition_tiles(const uint32_t *order, const float *cost, uint32_t 
 	}
 	begin_out[parts] = num_tiles;
 	return ACR_OK;
+}
+
+int acr_host_partition_tiles(const uint32_t *order, const float *cost, uint32_t num_tiles, uint32_t parts, uint32_t *begin_out)
+{
+	return acr_host_partition_tiles_weighted(order, cost, num_tiles, parts, nullptr, begin_out);
 }
 
 int acr_host_tile_order(uint32_t tiles_x, uint32_t tiles_y, uint32_t *order_out)

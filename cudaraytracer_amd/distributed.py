@@ -46,19 +46,24 @@ def tile_order(tiles_x, tiles_y):
     return out
 
 
-def partition(order, cost, parts):
-    """Cuts `order` into `parts` contiguous runs of near-equal summed cost
-    (cost None = uniform).  Returns parts+1 offsets into `order`."""
+def partition(order, cost, parts, weights=None):
+    """Cuts `order` into `parts` contiguous runs whose summed costs are in the ratio of `weights` (None = equal
+    shares; cost None = uniform cost).  Returns parts+1 offsets into `order`."""
     order = np.ascontiguousarray(order, dtype=np.uint32)
     begin = np.zeros(parts + 1, dtype=np.uint32)
-    cp = None
+    cp = wp = None
     if cost is not None:
         cost = np.ascontiguousarray(cost, dtype=np.float32)
         cp = cost.ctypes.data_as(_capi.c_float_p)
-    rc = _capi.host_lib().acr_host_partition_tiles(order.ctypes.data_as(_capi.c_u32_p), cp, len(order), parts,
-                                                   begin.ctypes.data_as(_capi.c_u32_p))
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        if len(weights) != parts:
+            raise ValueError("one weight per part")
+        wp = weights.ctypes.data_as(_capi.c_float_p)
+    rc = _capi.host_lib().acr_host_partition_tiles_weighted(order.ctypes.data_as(_capi.c_u32_p), cp, len(order), parts, wp,
+                                                            begin.ctypes.data_as(_capi.c_u32_p))
     if rc != 0:
-        raise RuntimeError("acr_host_partition_tiles failed")
+        raise RuntimeError("acr_host_partition_tiles_weighted failed")
     return begin
 
 
@@ -77,20 +82,70 @@ class TiledFrame:
         self.bands = self.tiles_x == 1 and tile_w == width
         self.order = np.arange(self.num_tiles, dtype=np.uint32) if self.bands else tile_order(self.tiles_x, self.tiles_y)
         self.cost = None           # per-tile cost of the last frame, indexed by tile id
+        self.weights = None        # share of the total cost each rank gets (None = equal shares)
         self.begin = partition(self.order, None, world_size)
 
     def reset(self):
-        """Camera moved and no history applies: back to the uniform split."""
+        """Camera moved and no history applies: back to uniform costs (the ranks' shares are a property of
+        the machine, not of the view, and stay)."""
         self.cost = None
-        self.begin = partition(self.order, None, self.world)
+        self.begin = partition(self.order, None, self.world, self.weights)
 
     def update(self, cost):
         """New per-tile costs (every rank passes the same vector)."""
         self.cost = np.asarray(cost, dtype=np.float32).copy()
-        self.begin = partition(self.order, self.cost, self.world)
+        self.begin = partition(self.order, self.cost, self.world, self.weights)
+
+    def set_weights(self, weights):
+        """Unequal shares (every rank passes the same vector): rank r gets weights[r] / sum of the total cost."""
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float32).copy()
+        self.begin = partition(self.order, self.cost, self.world, self.weights)
 
     def tiles_of(self, rank):
         return self.order[int(self.begin[rank]):int(self.begin[rank + 1])]
+
+
+def solve_shares(measurements, num_tiles):
+    """Shares of the frame (one weight per rank, summing to 1) that make every rank need the same time per frame.
+
+    measurements: the last one or two (bands per rank, times[rank] = [render seconds, send seconds]) taken at
+    different shares.  With frames in flight rank 0 needs its render time per frame and every other rank the
+    larger of its render and its send time.  One measurement: time is taken as proportional to the share.  Two:
+    each phase of each rank is modelled as fixed cost + cost per band (fitted through the two points, clamped to
+    non-negative values; a rank whose share did not change keeps the proportional model), and the common frame
+    time T is found by bisection so that the shares the ranks can do in T add up to the frame."""
+    share, times = measurements[-1]
+    world = len(share)
+    fixed = np.zeros((world, 2))
+    per_band = times / np.maximum(share, 1.0)[:, None]
+    if len(measurements) > 1:
+        share0, times0 = measurements[0]
+        for r in range(world):
+            ds = share[r] - share0[r]
+            if abs(ds) < 1.0:
+                continue
+            for ph in range(2):
+                c = (times[r, ph] - times0[r, ph]) / ds
+                o = times[r, ph] - c * share[r]
+                if c > 0 and o >= 0:
+                    per_band[r, ph], fixed[r, ph] = c, o
+    per_band = np.maximum(per_band, 1e-12)
+
+    def bands_within(t):
+        can = (t - fixed) / per_band                      # bands each phase gets through in t
+        b = np.minimum(can[:, 0], can[:, 1])
+        b[0] = can[0, 0]                                  # rank 0 sends nothing
+        return np.clip(b, 0.0, float(num_tiles))
+
+    lo, hi = 0.0, float(np.max(fixed) + np.max(per_band) * num_tiles)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if bands_within(mid).sum() >= num_tiles:
+            hi = mid
+        else:
+            lo = mid
+    b = bands_within(hi)
+    return b / b.sum()
 
 
 class DistributedRenderer:
@@ -144,6 +199,10 @@ class DistributedRenderer:
         self.frames_since_rebalance = 0
         self.last_cost = self.cost
         self._rays_last = torch.zeros((), dtype=torch.int64, device=device)
+        self._exchange_off = False
+        self._last_slot = 0
+        self.calibration = None
+        self._calibrations = []  # (bands per rank, [render s, send s] per rank) of each calibrate() call
 
     @property
     def frame(self):
@@ -176,6 +235,91 @@ class DistributedRenderer:
         """flat pixel range of bands [b0, b1) inside the frame (the last band may be cut by the frame's bottom edge)"""
         return b0 * self.tile_px, min(b1 * self.tile_px, self.width * self.height)
 
+    def _exchange(self, slot):
+        """Bands layout: posts the point-to-point exchange of the frame in buffer `slot` (rank 0 receives every
+        other rank's piece in place, the others send theirs); the handles go to self.pending[slot]."""
+        p = self.plan
+        flat = self.frames[slot].view(-1, 4)
+        px0, px1 = self._band_pixels(int(p.begin[self.rank]), int(p.begin[self.rank + 1]))
+        ops, staged = [], {}
+        if self.rank == 0:
+            for r in range(1, self.world):
+                q0, q1 = self._band_pixels(int(p.begin[r]), int(p.begin[r + 1]))
+                if q1 > q0:
+                    dst = flat[q0:q1]
+                    if self.stage_through_host:
+                        staged[r] = (torch.empty(dst.shape, dtype=dst.dtype), dst)
+                        dst = staged[r][0]
+                    ops.append(dist.P2POp(dist.irecv, dst, r))
+        elif px1 > px0:
+            out = flat[px0:px1]
+            ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if staged:
+            for w in works:
+                w.wait()
+            works = []
+            for buf, dst in staged.values():
+                dst.copy_(buf)
+        self.pending[slot] = works
+
+    def calibrate(self, frames=3):
+        """Measures how fast each rank gets its share done and sets the ranks' shares accordingly.
+
+        With frames in flight a rank other than 0 finishes a frame every max(render, send) and rank 0 every
+        render (it sends nothing); at kilohertz frame rates the send over one xGMI link takes longer than the
+        rendering, so equal shares would make the link the frame time.  Each of `frames` frames is run without
+        overlap -- barrier, render, wait, exchange, wait -- every rank times its two phases, the times are shared
+        with one all-reduce, and solve_shares() turns them into shares (call it two or three times: from the
+        second call on it has two measurements at different shares and can tell each phase's fixed cost from its
+        cost per band).  Bands layout only; a no-op for one rank.  The frames rendered here are ordinary frames."""
+        if self.world == 1 or not self.bands:
+            return None
+        import time
+        on_gpu = torch.device(self.device).type == "cuda"
+
+        def wait_all():
+            for slot in range(self.depth):
+                for w in self.pending[slot]:
+                    w.wait()
+                self.pending[slot] = []
+            if on_gpu:
+                torch.cuda.synchronize()
+
+        keep_every, self.rebalance_every = self.rebalance_every, 0
+        t_render = t_send = 0.0
+        for _ in range(max(1, frames)):
+            wait_all()
+            dist.barrier()
+            t0 = time.perf_counter()
+            self._exchange_off = True
+            self.render_frame()
+            self._exchange_off = False
+            wait_all()
+            t1 = time.perf_counter()
+            dist.barrier()
+            t2 = time.perf_counter()
+            self._exchange(self._last_slot)
+            wait_all()
+            t3 = time.perf_counter()
+            t_render += t1 - t0
+            t_send += t3 - t2
+        self.rebalance_every = keep_every
+        times = torch.zeros((self.world, 2), dtype=torch.float64)
+        times[self.rank, 0], times[self.rank, 1] = t_render, t_send
+        if not self.stage_through_host:
+            times = times.to(self.device)
+        dist.all_reduce(times)
+        times = times.cpu().numpy()
+        p = self.plan
+        share = np.array([int(p.begin[r + 1]) - int(p.begin[r]) for r in range(self.world)], dtype=np.float64)
+        times /= max(1, frames)
+        self._calibrations.append((share, times))
+        weights = solve_shares(self._calibrations[-2:], p.num_tiles)
+        p.set_weights(weights)
+        self.calibration = dict(render_s=times[:, 0], send_s=times[:, 1], weights=p.weights.copy())
+        return self.calibration
+
     def render_frame(self, want_cost=False):
         """One frame.  Returns the frame tensor on rank 0 (None elsewhere); with the bands layout its
         exchange may still be in flight until finish() or until `depth` more frames were started.
@@ -196,27 +340,9 @@ class DistributedRenderer:
             out = flat[px0:px1]
             if b1 > b0:
                 self.render_tiles(p.order[b0:b1], out, cost)
-            if self.world > 1:
-                ops, staged = [], {}
-                if self.rank == 0:
-                    for r in range(1, self.world):
-                        q0, q1 = self._band_pixels(int(p.begin[r]), int(p.begin[r + 1]))
-                        if q1 > q0:
-                            dst = flat[q0:q1]
-                            if self.stage_through_host:
-                                staged[r] = (torch.empty(dst.shape, dtype=dst.dtype), dst)
-                                dst = staged[r][0]
-                            ops.append(dist.P2POp(dist.irecv, dst, r))
-                elif px1 > px0:
-                    ops.append(dist.P2POp(dist.isend, out.cpu() if self.stage_through_host else out, 0))
-                works = dist.batch_isend_irecv(ops) if ops else []
-                if staged:
-                    for w in works:
-                        w.wait()
-                    works = []
-                    for buf, dst in staged.values():
-                        dst.copy_(buf)
-                self.pending[slot] = works
+            self._last_slot = slot
+            if self.world > 1 and not self._exchange_off:
+                self._exchange(slot)
         else:
             # rank 0 keeps its run at its Z position; other ranks use the front of their buffer
             at = b0 if self.rank == 0 else 0

@@ -144,6 +144,11 @@ int acr_host_renderer_save(acr_host_renderer *r, const char *path);
  * as possible.  cost == NULL means uniform cost: the reset state after a
  * camera move (renderer.cu:165,344-348).  begin_out gets parts+1 offsets into `order`. */
 int acr_host_partition_tiles(const uint32_t *order, const float *cost, uint32_t num_tiles, uint32_t parts, uint32_t *begin_out);
+/* The same with unequal shares: part k gets weights[k] / sum(weights) of the total cost (weights == NULL: equal
+ * shares).  Used when the parts do not work at the same speed: a GPU that also has to send its tiles to GPU 0
+ * finishes fewer of them per second than GPU 0 itself. */
+int acr_host_partition_tiles_weighted(const uint32_t *order, const float *cost, uint32_t num_tiles, uint32_t parts, const float *weights,
+                                      uint32_t *begin_out);
 /* Morton (Z-curve) visiting order of a tiles_x * tiles_y grid. */
 int acr_host_tile_order(uint32_t tiles_x, uint32_t tiles_y, uint32_t *order_out);
 

@@ -47,6 +47,9 @@ def _worker(rank, world, port, out_path, layout):
     def render_tiles(tile_ids, out, cost):
         # stand-in for the GPU core: render the frame on the CPU, cut out this rank's tiles in the compact
         # layout [tile][row][column] the kernel writes (`out` may end before the last tile's last rows)
+        if state.get("slow_rank", -1) == rank:
+            import time
+            time.sleep(0.5)
         r = o.render(W, H, seed=state["seed"], frames=0, max_bounces=2, threads=2)
         img = r["screen"]
         tiles_x = (W + tw - 1) // tw
@@ -89,6 +92,24 @@ def _worker(rank, world, port, out_path, layout):
             prev = dr.frames[(dr.frame_no - 2) % dr.depth]
             ref = o.render(W, H, seed=32, frames=0, max_bounces=2, threads=2)["screen"]
             results["equal_pipelined"] &= bool(np.array_equal(prev.numpy().view(np.uint32), ref.view(np.uint32)))
+    if layout == "bands":
+        # shares from measured speed: rank 1 is made slow, must get the smaller share, every rank derives the
+        # same split, and the frame assembled under it is still the full-frame render
+        state["slow_rank"] = 1
+        cal = dr.calibrate(frames=2)
+        state["slow_rank"] = -1
+        begins = [None, None]
+        dist.all_gather_object(begins, [int(x) for x in dr.plan.begin])
+        assert begins[0] == begins[1]
+        state["seed"] = 41
+        dr.camera_moved()  # costs back to uniform; the shares stay
+        dr.render_frame()
+        frame = dr.finish()
+        if rank == 0:
+            ref = o.render(W, H, seed=41, frames=0, max_bounces=2, threads=2)["screen"]
+            results["equal_weighted"] = bool(np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32)))
+            results["weights"] = [float(x) for x in cal["weights"]]
+            results["weighted_split"] = [int(x) for x in dr.plan.begin]
     if rank == 0:
         results["splits"] = splits
         results["rendered"] = rendered
@@ -108,6 +129,12 @@ def test_two_rank_frame_assembly(tmp_path, layout):
     n = s0[-1]
     assert s0[0] == 0 and s0[1] in (n // 2, (n + 1) // 2) and s0[2] == n and s2 == s0   # uniform at start and after the camera move
     assert s1 != s0 and s1[0] == 0 and s1[-1] == n    # rebalanced from the first frame's costs
+    if layout == "bands":
+        assert res["equal_weighted"]
+        w = res["weights"]
+        assert abs(sum(w) - 1.0) < 1e-5 and w[1] < w[0]
+        ws = res["weighted_split"]
+        assert ws[0] == 0 and ws[2] == n and ws[1] > n // 2   # the slow rank renders fewer bands
 
 
 def test_single_rank_path_without_process_group():

@@ -104,3 +104,26 @@ def test_tiled_frame_reset_and_update():
     assert max(loads) / (sum(loads) / 8) < 1.05
     p.reset()
     assert [len(p.tiles_of(r)) for r in range(8)] == sizes
+
+
+def test_weighted_partition_of_tiles():
+    """shares in the ratio of the weights; equal weights reproduce the unweighted split; bad weights are refused"""
+    from cudaraytracer_amd import _capi
+    from cudaraytracer_amd import distributed as D
+    order = np.arange(100, dtype=np.uint32)
+    assert list(D.partition(order, None, 4)) == [0, 25, 50, 75, 100]
+    assert list(D.partition(order, None, 4, [1, 1, 1, 1])) == [0, 25, 50, 75, 100]
+    assert list(D.partition(order, None, 4, [4, 2, 2, 2])) == [0, 40, 60, 80, 100]
+    assert list(D.partition(order, None, 2, [1, 0])) == [0, 100, 100]
+    cost = np.ones(100, np.float32)
+    cost[:50] = 3.0  # the first half of the tiles is three times as expensive
+    b = D.partition(order, cost, 2, [3, 1])  # 150 of the 200 cost units for part 0
+    assert list(b) == [0, 50, 100]
+    H = _capi.host_lib()
+    begin = np.zeros(3, np.uint32)
+    neg = np.array([1, -1], np.float32)
+    assert H.acr_host_partition_tiles_weighted(order.ctypes.data_as(_capi.c_u32_p), None, 100, 2, neg.ctypes.data_as(_capi.c_float_p),
+                                               begin.ctypes.data_as(_capi.c_u32_p)) != 0
+    zero = np.zeros(2, np.float32)
+    assert H.acr_host_partition_tiles_weighted(order.ctypes.data_as(_capi.c_u32_p), None, 100, 2, zero.ctypes.data_as(_capi.c_float_p),
+                                               begin.ctypes.data_as(_capi.c_u32_p)) != 0
