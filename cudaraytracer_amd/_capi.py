@@ -89,14 +89,14 @@ class Frame(C.Structure):
                 ("max_bounces", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("num_tiles", C.c_uint32), ("tile_ids", c_u32_p), ("pixel_values_dev", C.c_void_p),
                 ("collect_stats", C.c_uint32), ("tile_rays_dev", C.c_void_p), ("tile_cycles_dev", C.c_void_p),
-                ("path_keys_dev", C.c_void_p)]
+                ("path_keys_dev", C.c_void_p), ("block_order_dev", C.c_void_p)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("kernel_ms", C.c_float), ("lds_bytes", C.c_uint32),
                 ("scene_in_lds", C.c_uint32), ("grid_blocks", C.c_uint32), ("interval_traversal", C.c_uint32),
-                ("six_plane_pixels", C.c_uint32), ("near_first", C.c_uint32)]
+                ("six_plane_pixels", C.c_uint32), ("block_order", C.c_uint32), ("near_first", C.c_uint32)]
 
 
 # every symbol include/acr_hip.h declares: name -> (restype, argtypes)
@@ -108,6 +108,7 @@ HIP_SYMBOLS = {
     "acr_hip_use_own_stream": (C.c_int, [C.c_void_p]),
     "acr_hip_sync": (C.c_int, [C.c_void_p]),
     "acr_hip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
+    "acr_hip_set_block_order": (C.c_int, [C.c_void_p, C.c_uint32]),
     "acr_hip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneSoA)]),
     "acr_hip_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_hip_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),

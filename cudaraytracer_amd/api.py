@@ -155,13 +155,18 @@ class HipCore:
         six-plane form as written in the reference for every ray."""
         self._check(self._lib.acr_hip_set_traversal(self._h, 1 if six_plane_only else 0), "acr_hip_set_traversal")
 
+    def set_block_order(self, every):
+        """every > 0 (default 16): blocks of 16 x 16 pixels start most expensive first, re-measured on every
+        `every`-th launch; 0: natural order.  Frames do not depend on it."""
+        self._check(self._lib.acr_hip_set_block_order(self._h, every), "acr_hip_set_block_order")
+
     def resize(self, w, h):
         self._check(self._lib.acr_hip_resize(self._h, w, h), "acr_hip_resize")
         self._w, self._hh = w, h
 
     def render(self, width, height, seed=0, frames=0, max_bounces=1, collect_stats=False, screen_dev=None,
                primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None,
-               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None):
+               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None):
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
         f.collect_stats = 1 if collect_stats else 0
@@ -174,6 +179,7 @@ class HipCore:
         f.tile_rays_dev = tile_rays_dev
         f.tile_cycles_dev = tile_cycles_dev
         f.path_keys_dev = path_keys_dev
+        f.block_order_dev = block_order_dev
         self._check(self._lib.acr_hip_render(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render")
 
     def sync(self):

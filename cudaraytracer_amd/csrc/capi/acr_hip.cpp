@@ -71,6 +71,13 @@ struct acr_hip_ctx
 	size_t meshGlobBytes = 0;
 	uint32_t sceneDepthGiven = 0;  // MAX_DEPTH of the scene tree as uploaded (before unused levels were trimmed)
 	// scratch of acr_hip_sort_pixel_map
+	// launch order of the blocks of 16 x 16 pixel slots, from measured cost (acr_hip_set_block_order)
+	uint32_t blockOrderEvery = 16;
+	uint32_t *blockCost = nullptr, *blockOrder = nullptr;
+	size_t blockCap = 0;
+	uint64_t blockKey = 0;      // configuration (frame size, tile list) the order belongs to
+	bool blockOrderValid = false;
+	uint32_t blockOrderAge = 0; // launches since the order was measured
 	void *sortTemp = nullptr;
 	size_t sortTempBytes = 0;
 	uint64_t *sortKeysOut = nullptr;
@@ -86,6 +93,7 @@ namespace
 {
 	constexpr uint32_t kBlock = ACR_BLOCK;
 	constexpr uint32_t kSlots = ACR_BLOCK_SLOTS;
+	constexpr uint32_t kMinBlocksForOrder = 1024; // four workgroups per CU are resident at once: a smaller launch starts all its blocks together anyway
 	constexpr uint32_t kGroupsPerBlock = kSlots / kBlock; // workgroups per block of 16 x 16 pixel slots
 	constexpr uint32_t kBlockRows = kSlots / 16;
 	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
@@ -302,6 +310,8 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->redoCount);
 	(void)hipFree(ctx->redoList);
 	(void)hipFree(ctx->meshGlob);
+	(void)hipFree(ctx->blockCost);
+	(void)hipFree(ctx->blockOrder);
 	(void)hipFree(ctx->sortTemp);
 	(void)hipFree(ctx->sortKeysOut);
 	(void)hipFree(ctx->sortValuesIn);
@@ -326,6 +336,14 @@ int acr_hip_use_own_stream(acr_hip_ctx *ctx)
 {
 	if (!ctx) return ACR_ERR_INVALID;
 	ctx->stream = ctx->ownStream;
+	return ACR_OK;
+}
+
+int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every)
+{
+	if (!ctx) return ACR_ERR_INVALID;
+	ctx->blockOrderEvery = every;
+	ctx->blockOrderValid = false;
 	return ACR_OK;
 }
 
@@ -644,6 +662,42 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	p.tile_ids = ctx->renderTiles.dev;
 	p.pixel_values = f->pixel_values_dev;
 	p.path_keys = f->path_keys_dev;
+	// Launch order of the blocks: the caller's table, else the context's own (measured every blockOrderEvery-th
+	// launch of a configuration; small launches do not fill the GPU and are left alone).
+	if (tiled && f->block_order_dev) return fail(ctx, ACR_ERR_INVALID, "block_order_dev needs a full-frame launch");
+	const uint32_t numBlocks = grid / kGroupsPerBlock;
+	const bool ownOrder = ctx->blockOrderEvery != 0 && !f->block_order_dev && numBlocks >= kMinBlocksForOrder;
+	bool measureBlocks = false;
+	p.block_order = f->block_order_dev;
+	if (ownOrder) {
+		// FNV-1a over what decides which pixels a block holds
+		uint64_t key = 1469598103934665603ull;
+		auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+		mix(f->width); mix(f->height); mix(f->num_tiles); mix(f->tile_w); mix(f->tile_h);
+		for (uint32_t i = 0; i < f->num_tiles; i++) mix(f->tile_ids[i]);
+		if (key != ctx->blockKey) {
+			ctx->blockKey = key;
+			ctx->blockOrderValid = false;
+		}
+		if (ctx->blockCap < numBlocks) {
+			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder}) {
+				(void)hipFree(*b);
+				*b = nullptr;
+			}
+			ctx->blockCap = 0;
+			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder})
+				ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(b), size_t(numBlocks) * sizeof(uint32_t)));
+			ctx->blockCap = numBlocks;
+			ctx->blockOrderValid = false;
+		}
+		measureBlocks = !ctx->blockOrderValid || ctx->blockOrderAge + 1 >= ctx->blockOrderEvery;
+		if (ctx->blockOrderValid) p.block_order = ctx->blockOrder;
+		if (measureBlocks) {
+			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->blockCost, 0, size_t(numBlocks) * sizeof(uint32_t), ctx->stream));
+			p.block_cost = ctx->blockCost;
+		}
+	}
 	p.screen = ownBuffers ? ctx->screen : static_cast<float4 *>(screen_dev);
 	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
 	p.hit_t = hit_t_dev ? hit_t_dev : (ownBuffers ? ctx->hitT : nullptr);
@@ -697,7 +751,19 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	}
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, fast ? 1 : 0, grid, plan.ldsBytes, ctx->stream));
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
+	const uint32_t orderUsed = f->block_order_dev ? ACR_BLOCK_ORDER_CALLER : (p.block_order ? ACR_BLOCK_ORDER_MEASURED : ACR_BLOCK_ORDER_NATURAL);
+	if (ownOrder) {
+		if (measureBlocks) {
+			// most expensive first; the launch that was just queued has read the old table by the time this runs
+			ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->stream));
+			ctx->blockOrderValid = true;
+			ctx->blockOrderAge = 0;
+		} else {
+			ctx->blockOrderAge++;
+		}
+	}
 	ctx->stats = acr_stats{};
+	ctx->stats.block_order = orderUsed;
 	ctx->stats.lds_bytes = uint32_t(plan.ldsBytes);
 	ctx->stats.scene_in_lds = uint32_t(plan.ldsMode);
 	ctx->stats.grid_blocks = grid;

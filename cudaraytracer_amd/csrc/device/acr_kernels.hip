@@ -1162,19 +1162,24 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
 
 	const bool tiled = p.num_tiles != 0;
-	const uint64_t clock0 = (tiled && p.tile_cycles) ? __builtin_readcyclecounter() : 0;
+	const uint64_t clock0 = ((tiled && p.tile_cycles) || p.block_cost) ? __builtin_readcyclecounter() : 0;
 	// this workgroup's part of its block of pixel slots
 	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
-	const uint32_t vblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
+	const uint32_t gblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
+	// Workgroups start in grid order, so the order table decides which blocks start first: with the expensive ones
+	// first the launch does not end on a few long workgroups while the rest of the GPU is idle.
+	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
 	const SlotResult res = renderSlot<FAST, KEYS, ONE>(p, mem, vblock, vtid);
 	if constexpr (FAST) {
 		if (res.bail) {
 			const uint32_t at = atomicAdd(p.redo_count, 1u);
-			p.redo_list[at] = firstSlot + threadIdx.x;
+			p.redo_list[at] = vblock * kSlots + vtid;
 		}
 	}
 	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
 		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	if (p.block_cost && (threadIdx.x & 63u) == 0)
+		atomicAdd(&p.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
 	reportCounts(p, res, vblock);
 }
 
@@ -1276,6 +1281,36 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 	p.normal[3 * i] = info.normal.x; p.normal[3 * i + 1] = info.normal.y; p.normal[3 * i + 2] = info.normal.z;
 }
 
+// Launch order of a frame's blocks from their measured cost, most expensive first: one workgroup, a counting
+// sort into 256 cost classes (linear in cost / largest cost).  The order inside a class is whatever the atomics
+// make it; frames do not depend on the order at all.
+__global__ void __launch_bounds__(1024) orderBlocksKernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order)
+{
+	__shared__ uint32_t bins[256];
+	__shared__ uint32_t largest;
+	if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+	if (threadIdx.x == 0) largest = 1;
+	__syncthreads();
+	uint32_t m = 0;
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) m = cost[i] > m ? cost[i] : m;
+	atomicMax(&largest, m);
+	__syncthreads();
+	const uint64_t top = largest;
+	auto classOf = [top](uint32_t c) { return 255u - uint32_t(uint64_t(c) * 255u / top); };
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&bins[classOf(cost[i])], 1u);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t at = 0;
+		for (uint32_t k = 0; k < 256; k++) {
+			const uint32_t c = bins[k];
+			bins[k] = at;
+			at += c;
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&bins[classOf(cost[i])], 1u)] = i;
+}
+
 // compact tiles -> full frame (last step of the multi-GPU gather)
 __global__ void __launch_bounds__(kBlock) scatterTilesKernel(const float4 *__restrict__ tiles, const uint32_t *__restrict__ tileIds,
                                                              uint32_t tileW, uint32_t tileH, uint32_t tilesX, uint32_t width, uint32_t height,
@@ -1343,6 +1378,12 @@ __global__ void __launch_bounds__(256) iotaKernel(int32_t *values, uint32_t n)
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < n) values[i] = int32_t(i);
 }
+extern "C" hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream)
+{
+	hipLaunchKernelGGL(acr::dev::orderBlocksKernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
+	return hipGetLastError();
+}
+
 extern "C" hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream)
 {
 	hipLaunchKernelGGL(iotaKernel, dim3((n + 255) / 256), dim3(256), 0, stream, values, n);

@@ -59,6 +59,8 @@ namespace dev
 		uint32_t *redo_count_next;  // device: the counter the next frame will use; the list pass zeroes it
 		uint32_t *redo_list;        // device [grid * 256]
 		uint64_t *path_keys;        // device [width * height] or null: per-pixel traversal-path key (full-frame launches)
+		uint32_t *block_cost;        // device [blocks of the launch] or null: wave clock ticks spent per block, summed over its waves
+		const uint32_t *block_order; // device [blocks of the frame] or null: which block of 16 x 16 pixels the k-th block of the grid renders (full-frame launches)
 	};
 
 	// workgroups of the list pass
@@ -82,6 +84,8 @@ namespace dev
 extern "C" {
 hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream);
+// order[0..n) = the numbers 0..n-1, the ones with the largest cost[] first (256 cost classes)
+hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream);
 hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
                                         uint32_t width, uint32_t height, void *frame, hipStream_t stream);

@@ -160,6 +160,11 @@ typedef struct acr_frame {
 	 * items, 01 the other; renderer.cu:341,372).  Full-frame launches on scenes whose object tree was built with
 	 * MAX_DEPTH >= 6.  Input of acr_hip_sort_pixel_map. */
 	uint64_t *path_keys_dev;
+	/* Optional, full-frame launches only: device array with a permutation of the frame's blocks of 16 x 16
+	 * pixels (block b covers columns 16 * (b % ceil(width / 16)) ..., rows 16 * (b / ceil(width / 16)) ...):
+	 * the k-th workgroup group of the launch renders block block_order_dev[k].  Results do not depend on it;
+	 * it lets the caller choose which blocks start first (see acr_hip_set_block_order).  NULL: the context's order. */
+	const uint32_t *block_order_dev;
 } acr_frame;
 
 typedef struct acr_stats {
@@ -171,6 +176,7 @@ typedef struct acr_stats {
 	uint32_t grid_blocks;
 	uint32_t interval_traversal;   /* 1 when the last launch used the interval form (ACR_TRAVERSAL_AUTO on a qualifying scene) */
 	uint32_t six_plane_pixels;     /* pixels of that launch which were handed to the reference-order list pass (needs collect_stats) */
+	uint32_t block_order;          /* order in which that launch started its blocks of 16 x 16 pixel slots: ACR_BLOCK_ORDER_* */
 	uint32_t near_first;           /* 1 when that launch walked the mesh trees near side first (interval form, trees resident in HBM) */
 } acr_stats;
 
@@ -188,6 +194,18 @@ const char *acr_hip_last_error(const acr_hip_ctx *ctx);
 int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream);
 int acr_hip_use_own_stream(acr_hip_ctx *ctx);
 int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at renderer.cu:422 */
+
+/* Launch order of the blocks of 16 x 16 pixel slots.  The GPU starts workgroups in grid order and a launch ends
+ * with its last workgroups, so which blocks come last matters: if they are expensive ones, most of the GPU idles
+ * while they finish.  With every > 0 (default 16) the context measures the time per block on every `every`-th
+ * launch of a configuration (frame size, tile list) and starts the blocks of the following launches most
+ * expensive first.  This is the reference's adaptive assignment (a table consulted by the kernel and rebuilt from
+ * measured history on a cadence, renderer.cu:343-355,457-461) applied to the order of workgroups; frames do not
+ * depend on it.  every == 0: natural order.  acr_frame::block_order_dev overrides it for one launch. */
+#define ACR_BLOCK_ORDER_NATURAL  0
+#define ACR_BLOCK_ORDER_MEASURED 1
+#define ACR_BLOCK_ORDER_CALLER   2
+int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every);
 
 /* Chooses how BoundingBox::intersect (geometry.h:44-76) is evaluated during BIH traversal
  * (bih.h:241-248).  Results are identical either way; ACR_TRAVERSAL_SIX_PLANE exists so that

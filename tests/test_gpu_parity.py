@@ -627,3 +627,48 @@ def test_trees_whose_leaves_do_not_ascend_get_the_six_plane_kernel(core, acr, or
     finally:
         start[l], end[l], start[r], end[r] = keep
         core.upload_scene(s)
+
+
+def test_block_launch_order_does_not_change_frames(core, built, acr):
+    """The context starts the blocks of a launch most expensive first once it has measured them; a caller's table
+    can do the same.  Frames, ids and ray counts are those of the natural order (and the oracle's)."""
+    import torch
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 640, 480   # 1200 blocks of 16 x 16: above the size from which the order is used
+    ref = b.oracle.render(w, h, seed=5, frames=0, max_bounces=3)
+    core.set_block_order(0)
+    try:
+        img0, pid0, ht0, st0 = render(core, w, h, seed=5, frames=0, max_bounces=3)
+        assert st0.block_order == 0
+        assert_same(img0, pid0, ht0, st0, ref)
+    finally:
+        core.set_block_order(4)
+    seen = []
+    for k in range(6):   # launch 0 measures, 1..3 use the order, 4 measures again under the order, 5 uses the new one
+        img, pid, ht, st = render(core, w, h, seed=5, frames=0, max_bounces=3)
+        seen.append(st.block_order)
+        assert_same(img, pid, ht, st, ref)
+    assert seen == [0, 1, 1, 1, 1, 1]
+    # a caller's table: reverse order
+    nb = ((w + 15) // 16) * ((h + 15) // 16)
+    order = torch.arange(nb - 1, -1, -1, dtype=torch.int32, device="cuda:0")
+    core.resize(w, h)
+    core.render(w, h, seed=5, frames=0, max_bounces=3, collect_stats=True, block_order_dev=C.c_void_p(order.data_ptr()))
+    core.sync()
+    st = core.read_stats()
+    assert st.block_order == 2
+    assert_same(core.read_framebuffer(), core.read_primid(), core.read_hit_t(), st, ref)
+    # accumulation over frames under the measured order
+    acc = b.oracle.render(w, h, seed=7, frames=0, max_bounces=2)["screen"]
+    core.render(w, h, seed=7, frames=0, max_bounces=2)
+    for f in (1, 2):
+        acc = b.oracle.render(w, h, seed=7 + f, frames=f, max_bounces=2, screen=acc)["screen"]
+        core.render(w, h, seed=7 + f, frames=f, max_bounces=2)
+    core.sync()
+    assert np.array_equal(core.read_framebuffer().view(np.uint32), acc.view(np.uint32))
+    # a table cannot be combined with a tile list
+    with pytest.raises(Exception):
+        core.render(w, h, seed=5, frames=0, max_bounces=1, tile_ids=np.arange(4, dtype=np.uint32), tile_w=64, tile_h=16,
+                    block_order_dev=C.c_void_p(order.data_ptr()))
+    core.set_block_order(16)

@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--block-order", choices=["natural", "heavy-first", "reverse"], default="natural")
     ap.add_argument("--scene", default="cornell-box-cycles")
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--bounces", type=int, default=1)
@@ -84,6 +85,23 @@ def main():
         digest += "/" + hashlib.sha1(prim.cpu().numpy().tobytes() + ht.cpu().numpy().tobytes()).hexdigest()[:16]
     rays = st.rays_primary + st.rays_shadow + st.rays_bounce
 
+    if args.block_order != "natural":
+        # per-block cost of this frame from a tile-list launch with 16 x 16 tiles, then the order
+        bx, by = (w + 15) // 16, (h + 15) // 16
+        nb = bx * by
+        cyc = torch.zeros(nb, dtype=torch.int32, device=dev)
+        tiles = torch.zeros((nb, 256, 4), dtype=torch.float32, device=dev)
+        core.render(w, h, seed=777, frames=0, max_bounces=args.bounces, tile_ids=np.arange(nb, dtype=np.uint32), tile_w=16, tile_h=16,
+                    screen_dev=C.c_void_p(tiles.data_ptr()), tile_cycles_dev=C.c_void_p(cyc.data_ptr()))
+        core.sync()
+        cost = cyc.cpu().numpy().astype(np.int64)
+        order = np.argsort(-cost, kind="stable") if args.block_order == "heavy-first" else np.arange(nb)[::-1].copy()
+        order_dev = torch.from_numpy(order.astype(np.int32)).to(dev)
+        kw["block_order_dev"] = C.c_void_p(order_dev.data_ptr())
+        core.render(w, h, seed=777, frames=0, max_bounces=args.bounces, **kw)
+        torch.cuda.synchronize()
+        digest += "|" + hashlib.sha1(screen.cpu().numpy().tobytes()).hexdigest()[:16]
+        print("block cost: min %d median %d max %d" % (cost.min(), np.median(cost), cost.max()), file=sys.stderr)
     frames_of = lambda k: 0
     if args.accumulate:
         n = w * h
