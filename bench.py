@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--block-order-every", type=int, default=None, help="longest interval between block-order measurements (library default 64; 0 = natural order)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     WIDTH, HEIGHT, MAX_BOUNCES = wl["width"], wl["height"], wl["bounces"]
@@ -132,6 +133,8 @@ def main():
     core = acr.HipCore(local_rank)
     core.upload_scene(scene.soa)
     core.set_camera(scene.camera)
+    if args.block_order_every is not None:
+        core.set_block_order(args.block_order_every)
     cameras = camera_path.flythrough(scene.camera, wl["flythrough"]) if "flythrough" in wl else None
     # one explicit stream for kernels, torch events and RCCL ordering
     stream = torch.cuda.Stream(device)
@@ -165,23 +168,29 @@ def main():
             step()
         barrier()
         first_timed = step_no[0]
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        # HIP events around every 7th step only (a stride that does not lock onto the 16-launch cadence of the block-order measurement): an event costs the stream several microseconds, which is
+        # visible against a 0.2 ms frame
+        evs = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, 7)}
         t0 = time.perf_counter()
-        for a, b in evs:
-            a.record()
-            step()
-            b.record()
+        for k in range(args.steps):
+            if k in evs:
+                evs[k][0].record()
+                step()
+                evs[k][1].record()
+            else:
+                step()
         barrier()
         elapsed = time.perf_counter() - t0
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-        # rays of the timed frames, counted afterwards so that the timed launches carry no instrumentation
-        rays = 0
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs.values()]))
+        # rays of the timed frames, counted afterwards so that the timed launches carry no instrumentation: the
+        # same seeds and cameras back to back, the counters accumulating on the device, one read at the end
         for k in range(args.steps):
             if cameras:
                 core.set_camera(camera_of(first_timed + k))
-            core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr, collect_stats=True)
-            st = core.read_stats()
-            rays += st.rays_primary + st.rays_shadow + st.rays_bounce
+            core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr,
+                        collect_stats=1 if k == 0 else 2)
+        st = core.read_stats()
+        rays = st.rays_primary + st.rays_shadow + st.rays_bounce
         lds_bytes, lds_mode, interval, near_first = st.lds_bytes, st.scene_in_lds, st.interval_traversal, st.near_first
     else:
         def frame_args():

@@ -156,8 +156,8 @@ class HipCore:
         self._check(self._lib.acr_hip_set_traversal(self._h, 1 if six_plane_only else 0), "acr_hip_set_traversal")
 
     def set_block_order(self, every):
-        """every > 0 (default 16): blocks of 16 x 16 pixels start most expensive first, re-measured on every
-        `every`-th launch; 0: natural order.  Frames do not depend on it."""
+        """every > 0 (default 64): blocks of 16 x 16 pixels start most expensive first, re-measured at intervals
+        growing from 4 to `every` launches while the camera stays; 0: natural order.  Frames do not depend on it."""
         self._check(self._lib.acr_hip_set_block_order(self._h, every), "acr_hip_set_block_order")
 
     def resize(self, w, h):
@@ -169,7 +169,7 @@ class HipCore:
                tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None):
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
-        f.collect_stats = 1 if collect_stats else 0
+        f.collect_stats = int(collect_stats)  # False/True, or 2: counters accumulate over launches (ACR_STATS_ACCUMULATE)
         keep = None
         if tile_ids is not None:
             keep = np.ascontiguousarray(tile_ids, dtype=np.uint32)

@@ -72,7 +72,8 @@ struct acr_hip_ctx
 	uint32_t sceneDepthGiven = 0;  // MAX_DEPTH of the scene tree as uploaded (before unused levels were trimmed)
 	// scratch of acr_hip_sort_pixel_map
 	// launch order of the blocks of 16 x 16 pixel slots, from measured cost (acr_hip_set_block_order)
-	uint32_t blockOrderEvery = 16;
+	uint32_t blockOrderEvery = 64;   // longest interval between two measurements, in launches; 0 = natural order
+	uint32_t blockOrderInterval = 4; // current interval: 4 after a camera move, doubling while the view stays
 	uint32_t *blockCost = nullptr, *blockOrder = nullptr;
 	size_t blockCap = 0;
 	uint64_t blockKey = 0;      // configuration (frame size, tile list) the order belongs to
@@ -343,6 +344,7 @@ int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every)
 {
 	if (!ctx) return ACR_ERR_INVALID;
 	ctx->blockOrderEvery = every;
+	ctx->blockOrderInterval = 4;
 	ctx->blockOrderValid = false;
 	return ACR_OK;
 }
@@ -552,6 +554,8 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 int acr_hip_set_camera(acr_hip_ctx *ctx, const acr_camera *camera)
 {
 	if (!ctx || !camera) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	// a moved camera keeps the block order (neighbouring views cost alike) but has it re-measured soon
+	if (!ctx->haveCamera || memcmp(&ctx->camera, camera, sizeof(*camera)) != 0) ctx->blockOrderInterval = 4;
 	ctx->camera = *camera;
 	ctx->haveCamera = true;
 	return ACR_OK;
@@ -691,7 +695,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 			ctx->blockCap = numBlocks;
 			ctx->blockOrderValid = false;
 		}
-		measureBlocks = !ctx->blockOrderValid || ctx->blockOrderAge + 1 >= ctx->blockOrderEvery;
+		const uint32_t interval = ctx->blockOrderInterval < ctx->blockOrderEvery ? ctx->blockOrderInterval : ctx->blockOrderEvery;
+		measureBlocks = !ctx->blockOrderValid || ctx->blockOrderAge + 1 >= interval;
 		if (ctx->blockOrderValid) p.block_order = ctx->blockOrder;
 		if (measureBlocks) {
 			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->blockCost, 0, size_t(numBlocks) * sizeof(uint32_t), ctx->stream));
@@ -746,7 +751,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 
 	ctx->timed = f->collect_stats != 0;
 	if (ctx->timed) {
-		ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
+		if (f->collect_stats != ACR_STATS_ACCUMULATE)
+			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
 		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
 	}
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, fast ? 1 : 0, grid, plan.ldsBytes, ctx->stream));
@@ -758,6 +764,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 			ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->stream));
 			ctx->blockOrderValid = true;
 			ctx->blockOrderAge = 0;
+			if (ctx->blockOrderInterval < (1u << 30)) ctx->blockOrderInterval *= 2;
 		} else {
 			ctx->blockOrderAge++;
 		}

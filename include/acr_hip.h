@@ -144,7 +144,7 @@ typedef struct acr_frame {
 	 * device pointer to width*height ints or NULL for identity.  Reset to
 	 * identity by the kernel when frames == 0, as in the reference. */
 	int32_t *pixel_values_dev;
-	uint32_t collect_stats;        /* nonzero: count rays and time the kernel (acr_hip_read_stats) */
+	uint32_t collect_stats;        /* ACR_STATS_*: count rays and time the kernel (acr_hip_read_stats) */
 	/* Optional per-tile cost feedback for the next frame's tile assignment
 	 * (the measured counterpart of the reference's per-pixel path statistics,
 	 * renderer.cu:380,386,457-461): device uint32[num_tiles] each, zeroed by the
@@ -166,6 +166,11 @@ typedef struct acr_frame {
 	 * it lets the caller choose which blocks start first (see acr_hip_set_block_order).  NULL: the context's order. */
 	const uint32_t *block_order_dev;
 } acr_frame;
+
+/* acr_frame::collect_stats */
+#define ACR_STATS_OFF        0
+#define ACR_STATS_FRAME      1  /* counters of this launch alone */
+#define ACR_STATS_ACCUMULATE 2  /* counters keep what earlier launches added: totals of a run of frames with one read at its end */
 
 typedef struct acr_stats {
 	uint64_t rays_primary, rays_shadow, rays_bounce;   /* rays actually traced by the last render */
@@ -197,11 +202,13 @@ int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at rende
 
 /* Launch order of the blocks of 16 x 16 pixel slots.  The GPU starts workgroups in grid order and a launch ends
  * with its last workgroups, so which blocks come last matters: if they are expensive ones, most of the GPU idles
- * while they finish.  With every > 0 (default 16) the context measures the time per block on every `every`-th
- * launch of a configuration (frame size, tile list) and starts the blocks of the following launches most
- * expensive first.  This is the reference's adaptive assignment (a table consulted by the kernel and rebuilt from
- * measured history on a cadence, renderer.cu:343-355,457-461) applied to the order of workgroups; frames do not
- * depend on it.  every == 0: natural order.  acr_frame::block_order_dev overrides it for one launch. */
+ * while they finish.  With every > 0 (default 64) the context measures the time per block of a configuration
+ * (frame size, tile list) on its first launch, 4 launches later, then 8, 16 ... up to `every` launches later,
+ * and starts the blocks of the launches in between most expensive first; acr_hip_set_camera with a different
+ * camera keeps the table and puts the interval back to 4.  This is the reference's adaptive assignment (a table
+ * consulted by the kernel, rebuilt from measured history on a cadence, reconsidered when the camera moves:
+ * renderer.cu:343-355,457-461,165) applied to the order of workgroups; frames do not depend on it.
+ * every == 0: natural order.  acr_frame::block_order_dev overrides it for one launch. */
 #define ACR_BLOCK_ORDER_NATURAL  0
 #define ACR_BLOCK_ORDER_MEASURED 1
 #define ACR_BLOCK_ORDER_CALLER   2
