@@ -862,6 +862,7 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timed) {
+		static_assert(kCounterSlots * 4 * sizeof(unsigned long long) <= 65536, "read into a stack buffer");
 		unsigned long long slots[kCounterSlots * 4];
 		ACR_HIP_TRY(ctx, hipMemcpy(slots, ctx->counters, sizeof(slots), hipMemcpyDeviceToHost));
 		unsigned long long c[4] = {0, 0, 0, 0};

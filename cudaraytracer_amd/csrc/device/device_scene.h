@@ -49,7 +49,7 @@ namespace dev
 
 	// ray counters are spread over this many slots of 4 words so that the
 	// workgroups' atomic adds do not all land on one address
-	constexpr uint32_t kCounterSlots = 64;
+	constexpr uint32_t kCounterSlots = 2048; // many, so that the waves of a launch do not queue up on a few addresses
 
 	struct SceneHeader
 	{

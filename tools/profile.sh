@@ -2,14 +2,14 @@
 # Profiles one command with rocprofv3: one kernel-trace pass and separate counter passes (counters never
 # share a run with tracing).  Run on the GPU box:
 #   bash tools/profile.sh <tag> [program args...]     -> gpurun_out/prof_<tag>/
-# The default program is the headline bench: python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
+# The default program is the headline bench with its default step counts: python3 bench.py --no-cpu-baseline
 set -u
 TAG=${1:-r1}
 shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-if [ $# -eq 0 ]; then set -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline; fi
+if [ $# -eq 0 ]; then set -- python3 bench.py --no-cpu-baseline; fi
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- "$@" > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 pass() { # name counters...
   local name=$1; shift
