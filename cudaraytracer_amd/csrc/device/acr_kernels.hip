@@ -30,6 +30,14 @@
 //     sceneIntersect for why that cannot change the result.
 //   * Optionally the per-pixel traversal-path key of the reference's adaptive
 //     assignment (bih.h:13-27,268-274) is recorded (KEYS).
+//   * Mesh trees that are read from HBM (the deep ones) are walked near side
+//     first, with exact ties and order-dependent cases settled the reference's
+//     way; see "Near-side-first traversal" below.
+//   * Which block of 16 x 16 pixels a workgroup renders comes from a table
+//     (RenderParams::block_order), so that the host can start the expensive
+//     blocks first; renderKernel also measures the time per block for it.
+//   * renderKernel has a variant for max_bounces == 1 (ONE), the counterpart
+//     of the reference's compile-time MAX_BOUNCES (renderer.cu:10).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math).
 #include <hip/hip_runtime.h>
