@@ -653,14 +653,14 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // rotation * uniform scale transforms, where the reference's local ray is the
 // true image of the world ray.
 // `tLimit` also drops an object whose grown box the ray enters no nearer than
-// tLimit: the world-space t of any hit in it (scene.cu:431) exceeds that entry
-// distance by at least the margin, so with tLimit = info.t it could not replace
-// info (scene.cu:432).  The call would still return true there, so the caller
-// passes info.t only when that return value can no longer matter (a shadow
-// ray, or `intersected` already set) AND the ray direction has unit length, so
-// that slab distances are world distances like info.t (primary and shadow
-// rays are normalised; diffuse bounce directions are not, math.h:188-192);
-// FLT_MAX otherwise.
+// tLimit (a slab distance, i.e. in units of the ray parameter): the world-space
+// t of any hit in it (scene.cu:431) exceeds the world distance of that entry
+// point by at least the margin, so with tLimit = info.t / |d| it could not
+// replace info (scene.cu:432).  The call would still return true there, so the
+// caller passes that limit only when the return value can no longer matter (a
+// shadow ray, or `intersected` already set), FLT_MAX otherwise.  |d| is 1 for
+// primary and shadow rays, which are normalised; bounce directions are not
+// (math.h:188-192), so the caller measures them.
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
 template <bool FULL, bool FAST, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
@@ -752,7 +752,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
 template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               const Columns &col, bool &bail, PathRec *path = nullptr, bool unitDir = false)
+                                               const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f)
 {
 	SlabArgs sa;
 	sa.init(r);
@@ -768,7 +768,7 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
 	auto leaf = [&](uint32_t start, uint32_t end) {
 		for (uint32_t i = start; i < end; i++) {
-			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (unitDir && (SHADOW || intersected)) ? info.t : FLT_MAX);
+			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (distPerT != 0.0f && (SHADOW || intersected)) ? info.t * distPerT : FLT_MAX);
 			if constexpr (FAST) {
 				if (bail) return true;
 			}
@@ -872,7 +872,7 @@ __device__ __forceinline__ vec3 lightPoint(const Mem &mem, const SceneHeader &sc
 			WorldHit sh;
 			sh.t = t;
 			cnt.shadow++;
-			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, col, bail, nullptr, true))
+			if (sceneIntersect<true, FAST>(mem, sc, sr, sh, t, col, bail, nullptr, 1.0f))
 				c = vec3(0, 0, 0);
 			if constexpr (FAST) {
 				if (bail) return light;
@@ -1026,10 +1026,11 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if constexpr (KEYS) {
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
-			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, true);
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f);
 			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail);
 		} else {
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0);
+			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d));
 		}
 		if (FAST && bail) break;
 		if (!hit)
