@@ -679,7 +679,10 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
 		mix(f->width); mix(f->height); mix(f->num_tiles); mix(f->tile_w); mix(f->tile_h);
 		for (uint32_t i = 0; i < f->num_tiles; i++) mix(f->tile_ids[i]);
-		if (key != ctx->blockKey) {
+		// a configuration is measured from its second launch in a row on: a caller that changes its tile list
+		// with every launch (per-frame rebalancing across GPUs) would pay for tables it never uses
+		const bool repeated = key == ctx->blockKey;
+		if (!repeated) {
 			ctx->blockKey = key;
 			ctx->blockOrderValid = false;
 		}
@@ -696,7 +699,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 			ctx->blockOrderValid = false;
 		}
 		const uint32_t interval = ctx->blockOrderInterval < ctx->blockOrderEvery ? ctx->blockOrderInterval : ctx->blockOrderEvery;
-		measureBlocks = !ctx->blockOrderValid || ctx->blockOrderAge + 1 >= interval;
+		measureBlocks = repeated && (!ctx->blockOrderValid || ctx->blockOrderAge + 1 >= interval);
 		if (ctx->blockOrderValid) p.block_order = ctx->blockOrder;
 		if (measureBlocks) {
 			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->blockCost, 0, size_t(numBlocks) * sizeof(uint32_t), ctx->stream));

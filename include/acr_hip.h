@@ -203,7 +203,7 @@ int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at rende
 /* Launch order of the blocks of 16 x 16 pixel slots.  The GPU starts workgroups in grid order and a launch ends
  * with its last workgroups, so which blocks come last matters: if they are expensive ones, most of the GPU idles
  * while they finish.  With every > 0 (default 64) the context measures the time per block of a configuration
- * (frame size, tile list) on its first launch, 4 launches later, then 8, 16 ... up to `every` launches later,
+ * (frame size, tile list) on its second launch in a row, 4 launches later, then 8, 16 ... up to `every` launches later,
  * and starts the blocks of the launches in between most expensive first; acr_hip_set_camera with a different
  * camera keeps the table and puts the interval back to 4.  This is the reference's adaptive assignment (a table
  * consulted by the kernel, rebuilt from measured history on a cadence, reconsidered when the camera moves:
