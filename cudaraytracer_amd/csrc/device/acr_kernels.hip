@@ -1207,8 +1207,10 @@ __global__ void __launch_bounds__(kBlock) renderListKernel(const RenderParams p)
 	mem.g = p.blob;
 	if constexpr (LARGE_LDS) stageScene(p.blob, sc.total_slots);
 	else if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
-	for (uint32_t base = blockIdx.x * kBlock; base < count; base += gridDim.x * kBlock) {
-		const uint32_t k = base + threadIdx.x;
+	// Entry k goes to workgroup k % gridDim, work-item k / gridDim: a short list is spread one pixel per workgroup
+	// (a pixel alone in its wave is the fastest it can be), a long one fills the workgroups evenly.
+	for (uint32_t base = blockIdx.x; base < count; base += gridDim.x * kBlock) {
+		const uint32_t k = base + gridDim.x * threadIdx.x;
 		SlotResult res;
 		res.active = false;
 		res.bail = false;
