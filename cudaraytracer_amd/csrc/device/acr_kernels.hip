@@ -100,15 +100,15 @@ struct Ray { vec3 o, d; };
 struct SlabArgs
 {
 	vec3 o, invD;
-	bool sx, sy, sz;
 	__device__ __forceinline__ void init(const Ray &r)
 	{
 		o = r.o;
 		invD = 1.0f / r.d;
-		sx = invD.x < 0;
-		sy = invD.y < 0;
-		sz = invD.z < 0;
 	}
+	// the sign array of geometry.h:84-86, compared when needed instead of kept in three more registers
+	__device__ __forceinline__ bool sx() const { return invD.x < 0; }
+	__device__ __forceinline__ bool sy() const { return invD.y < 0; }
+	__device__ __forceinline__ bool sz() const { return invD.z < 0; }
 	__device__ __forceinline__ bool sign(uint32_t axis) const { return invD[int(axis)] < 0; }
 	// (bound - o) * invD on one axis: the per-plane term of geometry.h:52-66
 	__device__ __forceinline__ float plane(uint32_t axis, float bound) const { return (bound - o[int(axis)]) * invD[int(axis)]; }
@@ -123,8 +123,8 @@ struct SlabBox
 	{
 		const vec3 tmn = (mn - a.o) * a.invD;
 		const vec3 tmx = (mx - a.o) * a.invD;
-		nearT = vec3(a.sx ? tmx.x : tmn.x, a.sy ? tmx.y : tmn.y, a.sz ? tmx.z : tmn.z);
-		farT = vec3(a.sx ? tmn.x : tmx.x, a.sy ? tmn.y : tmx.y, a.sz ? tmn.z : tmx.z);
+		nearT = vec3(a.sx() ? tmx.x : tmn.x, a.sy() ? tmx.y : tmn.y, a.sz() ? tmx.z : tmn.z);
+		farT = vec3(a.sx() ? tmn.x : tmx.x, a.sy() ? tmn.y : tmx.y, a.sz() ? tmn.z : tmx.z);
 	}
 };
 
@@ -292,8 +292,8 @@ __device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &m
 	const vec3 tmn = (mn - a.o) * a.invD;
 	const vec3 tmx = (mx - a.o) * a.invD;
 	Interval r;
-	r.tmin = fmax3(a.sx ? tmx.x : tmn.x, a.sy ? tmx.y : tmn.y, a.sz ? tmx.z : tmn.z);
-	r.tmax = fmin3(a.sx ? tmn.x : tmx.x, a.sy ? tmn.y : tmx.y, a.sz ? tmn.z : tmx.z);
+	r.tmin = fmax3(a.sx() ? tmx.x : tmn.x, a.sy() ? tmx.y : tmn.y, a.sz() ? tmx.z : tmn.z);
+	r.tmax = fmin3(a.sx() ? tmn.x : tmx.x, a.sy() ? tmn.y : tmx.y, a.sz() ? tmn.z : tmx.z);
 	return r;
 }
 __device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) { return tmin <= tmax && tmin < tcur && tmax > epsilon(); }
