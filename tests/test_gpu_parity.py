@@ -672,3 +672,22 @@ def test_block_launch_order_does_not_change_frames(core, built, acr):
         core.render(w, h, seed=5, frames=0, max_bounces=1, tile_ids=np.arange(4, dtype=np.uint32), tile_w=64, tile_h=16,
                     block_order_dev=C.c_void_p(order.data_ptr()))
     core.set_block_order(64)
+
+
+def test_accumulating_ray_counters(core, built):
+    """collect_stats = 2 keeps what earlier launches counted: three frames, one read, the oracle's three totals."""
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 320, 180
+    core.resize(w, h)
+    want = [0, 0, 0, 0]
+    for k, seed in enumerate((3, 4, 5)):
+        core.render(w, h, seed=seed, frames=0, max_bounces=2, collect_stats=1 if k == 0 else 2)
+        c = b.oracle.render(w, h, seed=seed, frames=0, max_bounces=2, aov=False)["counters"]
+        for i, n in enumerate(("rays_primary", "rays_shadow", "rays_bounce", "primary_hits")):
+            want[i] += c[n]
+    st = core.read_stats()
+    assert [st.rays_primary, st.rays_shadow, st.rays_bounce, st.primary_hits] == want
+    core.render(w, h, seed=5, frames=0, max_bounces=2, collect_stats=1)   # 1 starts from zero again
+    st = core.read_stats()
+    assert st.rays_primary == w * h

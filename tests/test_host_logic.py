@@ -127,3 +127,38 @@ def test_weighted_partition_of_tiles():
     zero = np.zeros(2, np.float32)
     assert H.acr_host_partition_tiles_weighted(order.ctypes.data_as(_capi.c_u32_p), None, 100, 2, zero.ctypes.data_as(_capi.c_float_p),
                                                begin.ctypes.data_as(_capi.c_u32_p)) != 0
+
+
+def test_shares_from_measured_times():
+    """solve_shares: equal time per frame for every rank; rank 0 (which sends nothing) gets the largest piece when
+    sending costs more than rendering; one measurement = proportional model, two = fixed cost + cost per band"""
+    from cudaraytracer_amd.distributed import solve_shares
+
+    def measure(bands, render_fixed=5e-6, render_per=3.2e-6, send_fixed=20e-6, send_per=9.7e-6):
+        bands = np.asarray(bands, float)
+        t = np.zeros((len(bands), 2))
+        t[:, 0] = render_fixed + render_per * bands
+        t[:, 1] = send_fixed + send_per * bands
+        t[0, 1] = 0.0
+        return bands, t
+
+    def frame_times(w, n=68):
+        b, t = measure(w * n)
+        per = np.maximum(t[:, 0], t[:, 1])
+        per[0] = t[0, 0]
+        return per
+
+    for world in (2, 4, 8):
+        first = measure([68.0 / world] * world)
+        w1 = solve_shares([first], 68)
+        assert abs(w1.sum() - 1) < 1e-9 and w1[0] > w1[1] and np.allclose(w1[1:], w1[1])
+        second = measure(np.round(w1 * 68))
+        w2 = solve_shares([first, second], 68)
+        per = frame_times(w2)
+        assert per.max() / per.min() < 1.02           # the affine model is exact here: every rank takes the same time
+        assert frame_times(w2).max() < frame_times(np.full(world, 1.0 / world)).max()   # better than equal shares
+    # a rank that cannot send at all ends up with nothing, the others share the frame
+    b, t = measure([17.0] * 4)
+    t[2, 1] = 10.0
+    w = solve_shares([(b, t)], 68)
+    assert w[2] < 1e-3 and abs(w.sum() - 1) < 1e-9
