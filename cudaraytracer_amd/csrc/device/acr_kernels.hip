@@ -444,6 +444,9 @@ __device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, const SlabArg
 		uint4 n = loadNode(idx);
 		bool alive = true;
 		while ((n.w & kNodeLeafBit) == 0) {
+			// Both children of an internal node exist (checked at upload) and sit next to each other in the heap
+			// order: they are requested before this node's arithmetic, which then hides most of their way from L2.
+			const uint4 childL = loadNode(2 * idx + 1), childR = loadNode(2 * idx + 2);
 			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
 			const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
 			const bool sg = ia < 0;
@@ -462,13 +465,17 @@ __device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, const SlabArg
 				}
 				if (hitNearSide) tmaxB = nearSideMax;
 				else tminB = farSideMin;
-				idx = 2 * idx + ((hitNearSide != sg) ? 1 : 2); // the near-side child is the left one for a positive direction
+				const bool goLeft = hitNearSide != sg; // the near-side child is the left one for a positive direction
+				idx = 2 * idx + (goLeft ? 1 : 2);
 				level++;
-			} else if (!popNear(stack, pending, idx, level, tminB, tmaxB, tc)) {
-				alive = false;
-				break;
+				n = goLeft ? childL : childR;
+			} else {
+				if (!popNear(stack, pending, idx, level, tminB, tmaxB, tc)) {
+					alive = false;
+					break;
+				}
+				n = loadNode(idx);
 			}
-			n = loadNode(idx);
 		}
 		if (!alive)
 			return;
