@@ -634,15 +634,17 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 			test(i, mem.large(ts), mem.large(ts + 1), mem.large(ts + 2));
 		}
 	} else {
-		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so two records are fetched per
-		// trip (the second one again when the leaf holds an odd number) and tested in item order.
-		for (uint32_t i = start; i < end; i += 2) {
-			const uint32_t i1 = i + 1 < end ? i + 1 : i;
-			const uint32_t ts = triBase + i * kTriSlots, ts1 = triBase + i1 * kTriSlots;
+		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so three records are fetched per
+		// trip (the first one again where the leaf has no more) and tested in item order.  Four bring nothing more.
+		for (uint32_t i = start; i < end; i += 3) {
+			const uint32_t i1 = i + 1 < end ? i + 1 : i, i2 = i + 2 < end ? i + 2 : i;
+			const uint32_t ts = triBase + i * kTriSlots, ts1 = triBase + i1 * kTriSlots, ts2 = triBase + i2 * kTriSlots;
 			const uint4 a0 = mem.large(ts), a1 = mem.large(ts + 1), a2 = mem.large(ts + 2);
 			const uint4 b0 = mem.large(ts1), b1 = mem.large(ts1 + 1), b2 = mem.large(ts1 + 2);
+			const uint4 c0 = mem.large(ts2), c1 = mem.large(ts2 + 1), c2 = mem.large(ts2 + 2);
 			test(i, a0, a1, a2);
 			if (i1 != i) test(i1, b0, b1, b2);
+			if (i2 != i) test(i2, c0, c1, c2);
 		}
 	}
 }
