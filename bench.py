@@ -200,7 +200,8 @@ def main():
             step_no[0] += 1
             return a
         TILE_W = WIDTH
-        dr = D.DistributedRenderer(WIDTH, HEIGHT, D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args), device,
+        render_bands = D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args, cost_kind="cycles")
+        dr = D.DistributedRenderer(WIDTH, HEIGHT, render_bands, device,
                                    tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
                                    rebalance_every=1 if cameras else 16, stage_through_host=rehearsal)
         # Shares of the frame from measured speed (untimed, before the warm-up): a rank that has to send its piece
@@ -228,6 +229,7 @@ def main():
         # counts switched on (the total does not depend on how the frame is split)
         ray_sums = []
         dr.rebalance_every = 0
+        render_bands.cost_kind = "rays"
         step_no[0] = first_timed
         for _ in range(args.steps):
             dr.render_frame(want_cost=True)

@@ -397,13 +397,20 @@ class DistributedRenderer:
         return self._rays_last
 
 
-def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args):
+def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args, cost_kind="cycles"):
     """render_tiles callable over a HipCore: renders straight into the torch tensors' device memory through
-    the C ABI; the per-tile cost is the number of rays traced."""
+    the C ABI.  The per-tile cost is `fn.cost_kind` (an attribute the caller may change between frames):
+    "cycles", the wave clock ticks spent in the tile -- what balancing wants, since a ray through the floor of the
+    Cornell box costs ten times one to its ceiling -- or "rays", the number of rays traced, for counting."""
     def fn(tile_ids, out, cost):
         args = frame_args() if callable(frame_args) else dict(frame_args)
+        ptr = None if cost is None else C.c_void_p(cost.data_ptr())
         core.render(width, height, tile_ids=tile_ids, tile_w=tile_w, tile_h=tile_h, screen_dev=C.c_void_p(out.data_ptr()),
-                    tile_rays_dev=None if cost is None else C.c_void_p(cost.data_ptr()), **args)
+                    tile_rays_dev=ptr if fn.cost_kind == "rays" else None,
+                    tile_cycles_dev=ptr if fn.cost_kind == "cycles" else None, **args)
+    if cost_kind not in ("cycles", "rays"):
+        raise ValueError("cost_kind is 'cycles' or 'rays'")
+    fn.cost_kind = cost_kind
     return fn
 
 
