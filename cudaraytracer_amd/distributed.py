@@ -405,6 +405,9 @@ def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args, cost_kind=
     def fn(tile_ids, out, cost):
         args = frame_args() if callable(frame_args) else dict(frame_args)
         ptr = None if cost is None else C.c_void_p(cost.data_ptr())
+        # the launch goes onto torch's current stream of the output's device: the exchange (RCCL) and the torch
+        # operations on `out` and `cost` that follow are ordered against that stream
+        core.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
         core.render(width, height, tile_ids=tile_ids, tile_w=tile_w, tile_h=tile_h, screen_dev=C.c_void_p(out.data_ptr()),
                     tile_rays_dev=ptr if fn.cost_kind == "rays" else None,
                     tile_cycles_dev=ptr if fn.cost_kind == "cycles" else None, **args)

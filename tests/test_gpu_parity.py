@@ -691,3 +691,44 @@ def test_accumulating_ray_counters(core, built):
     core.render(w, h, seed=5, frames=0, max_bounces=2, collect_stats=1)   # 1 starts from zero again
     st = core.read_stats()
     assert st.rays_primary == w * h
+
+
+def test_band_renderer_on_one_gpu(core, built, acr):
+    """DistributedRenderer over the HIP core without a process group (one rank): frames rendered band by band into
+    frame-shaped memory equal the full-frame render; per-band costs come back as clock ticks or as ray counts."""
+    import torch
+    from cudaraytracer_amd import distributed as D
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 640, 360
+    dev = torch.device("cuda", 0)
+    seeds = iter(range(100, 200))
+    state = {}
+
+    def frame_args():
+        state["seed"] = next(seeds)
+        return dict(seed=state["seed"], frames=0, max_bounces=2)
+
+    bands = D.hip_render_tiles(core, w, h, w, 16, frame_args, cost_kind="cycles")
+    dr = D.DistributedRenderer(w, h, bands, dev, tile_w=w, tile_h=16, rebalance_every=2)
+    assert dr.bands and dr.world == 1
+    for k in range(4):
+        frame = dr.render_frame()
+        dr.finish()
+        core.sync()
+        ref = b.oracle.render(w, h, seed=state["seed"], frames=0, max_bounces=2, aov=False)
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), ref["screen"].view(np.uint32))
+    ticks = dr.last_cost.cpu().numpy()
+    bands.cost_kind = "rays"
+    dr.rebalance_every = 0
+    dr.render_frame(want_cost=True)
+    core.sync()
+    rays = int(dr.rays_last_frame().item())
+    c = b.oracle.render(w, h, seed=state["seed"], frames=0, max_bounces=2, aov=False)["counters"]
+    assert rays == c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+    assert calibrate_is_noop(dr)
+    core.use_own_stream()  # hip_render_tiles moved the shared context onto torch's stream
+
+
+def calibrate_is_noop(dr):
+    return dr.calibrate() is None
