@@ -63,6 +63,7 @@ struct acr_hip_ctx
 	bool intervalOk = false;
 	bool leafOrderOk = false; // near-side-first walks of mesh trees can break exact ties by item position
 	int traversalMode = ACR_TRAVERSAL_AUTO;
+	uint32_t listAllCount = 0; // ACR_TRAVERSAL_LIST_PASS: source of the copy that sets the list's length
 	uint32_t *redoCount = nullptr; // device [2], used alternately by successive frames
 	uint32_t *redoList = nullptr;
 	size_t redoCap = 0;
@@ -351,7 +352,8 @@ int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every)
 
 int acr_hip_set_traversal(acr_hip_ctx *ctx, int mode)
 {
-	if (!ctx || (mode != ACR_TRAVERSAL_AUTO && mode != ACR_TRAVERSAL_SIX_PLANE)) return fail(ctx, ACR_ERR_INVALID, "unknown traversal mode");
+	if (!ctx || (mode != ACR_TRAVERSAL_AUTO && mode != ACR_TRAVERSAL_SIX_PLANE && mode != ACR_TRAVERSAL_LIST_PASS))
+		return fail(ctx, ACR_ERR_INVALID, "unknown traversal mode");
 	ctx->traversalMode = mode;
 	return ACR_OK;
 }
@@ -719,7 +721,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
 	// the interval form walks mesh trees that are not LDS-resident near side first, which needs leafOrderOk
-	const bool fast = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && (plan.ldsMode == 2 || ctx->leafOrderOk);
+	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
+	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
 	if (fast && plan.meshGlobLevels) {
 		const size_t slots = size_t(grid) * kBlock;
 		if (slots >= (1ull << 32)) return fail(ctx, ACR_ERR_UNSUPPORTED, "launch too large for a mesh tree this deep");
@@ -758,7 +761,18 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
 		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
 	}
-	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, fast ? 1 : 0, grid, plan.ldsBytes, ctx->stream));
+	if (listOnly) {
+		// every slot of the launch goes onto the list; only the list pass runs
+		const uint32_t slots = grid * kBlock;
+		if (p.path_keys || p.tile_cycles) return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
+		ACR_HIP_TRY(ctx, acr_dev_launch_iota(reinterpret_cast<int32_t *>(p.redo_list), slots, ctx->stream));
+		ctx->listAllCount = slots; // the copy below may read it after this call returned
+		ACR_HIP_TRY(ctx, hipMemcpyAsync(p.redo_count, &ctx->listAllCount, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		p.block_order = nullptr;
+		p.block_cost = nullptr;
+		measureBlocks = false;
+	}
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (fast ? 1 : 0), grid, plan.ldsBytes, ctx->stream));
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
 	const uint32_t orderUsed = f->block_order_dev ? ACR_BLOCK_ORDER_CALLER : (p.block_order ? ACR_BLOCK_ORDER_MEASURED : ACR_BLOCK_ORDER_NATURAL);
 	if (ownOrder) {
@@ -778,7 +792,7 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	ctx->stats.scene_in_lds = uint32_t(plan.ldsMode);
 	ctx->stats.grid_blocks = grid;
 	ctx->stats.interval_traversal = fast ? 1u : 0u;
-	ctx->stats.near_first = (fast && plan.ldsMode != 2) ? 1u : 0u;
+	ctx->stats.near_first = (fast && !listOnly && plan.ldsMode != 2) ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }

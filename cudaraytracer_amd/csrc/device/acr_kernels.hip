@@ -1364,8 +1364,9 @@ namespace
 	}
 } // namespace
 
-// fast != 0: interval traversal for the whole grid, then the six-plane list pass over whatever it handed back
-// (p->redo_* must be set).  fast == 0: six-plane traversal for the whole grid.  p->path_keys selects the
+// fast == 1: interval traversal for the whole grid, then the list pass over whatever it handed back
+// (p->redo_* must be set).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
+// traversal for the whole grid.  p->path_keys selects the
 // variants that also record the per-pixel traversal-path key.
 template <bool KEYS>
 static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)
@@ -1376,6 +1377,8 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 		K k = ldsMode == 2 ? renderKernel<true, true, false, KEYS> : (ldsMode == 1 ? renderKernel<true, false, false, KEYS> : renderKernel<false, false, false, KEYS>);
 		return launchWithLds(k, *p, grid, ldsBytes, stream);
 	}
+	K kl = ldsMode == 2 ? renderListKernel<true, true, KEYS> : (ldsMode == 1 ? renderListKernel<true, false, KEYS> : renderListKernel<false, false, KEYS>);
+	if (fast == 2) return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream); // the caller has listed every slot
 	K k = ldsMode == 2 ? renderKernel<true, true, true, KEYS> : (ldsMode == 1 ? renderKernel<true, false, true, KEYS> : renderKernel<false, false, true, KEYS>);
 	if constexpr (!KEYS) {
 		if (p->max_bounces == 1)
@@ -1383,7 +1386,6 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 	}
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
-	K kl = ldsMode == 2 ? renderListKernel<true, true, KEYS> : (ldsMode == 1 ? renderListKernel<true, false, KEYS> : renderListKernel<false, false, KEYS>);
 	return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream);
 }
 

@@ -48,6 +48,8 @@ extern "C" {
 
 #define ACR_TRAVERSAL_AUTO      0  /* interval form of the slab test where it is provably identical, six-plane form elsewhere */
 #define ACR_TRAVERSAL_SIX_PLANE 1  /* the slab test exactly as written (geometry.h:44-76) for every ray */
+#define ACR_TRAVERSAL_LIST_PASS 2  /* every pixel through the pass that normally renders only the listed ones: the interval form in the
+                                     reference's visiting order, the six-plane form for the rays it cannot serve; slow, for tests */
 
 typedef struct acr_hip_ctx acr_hip_ctx;
 
@@ -215,8 +217,8 @@ int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at rende
 int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every);
 
 /* Chooses how BoundingBox::intersect (geometry.h:44-76) is evaluated during BIH traversal
- * (bih.h:241-248).  Results are identical either way; ACR_TRAVERSAL_SIX_PLANE exists so that
- * tests can check exactly that.  Default ACR_TRAVERSAL_AUTO. */
+ * (bih.h:241-248).  Results are identical either way; ACR_TRAVERSAL_SIX_PLANE and ACR_TRAVERSAL_LIST_PASS
+ * exist so that tests can check exactly that.  Default ACR_TRAVERSAL_AUTO. */
 int acr_hip_set_traversal(acr_hip_ctx *ctx, int mode);
 
 /* ---- scene, camera, buffers -------------------------------------------- */

@@ -732,3 +732,25 @@ def test_band_renderer_on_one_gpu(core, built, acr):
 
 def calibrate_is_noop(dr):
     return dr.calibrate() is None
+
+
+@pytest.mark.parametrize("ntri,depth", [(60000, 14), (150, 6)])
+def test_whole_frames_through_the_list_pass(core, acr, orc, ntri, depth):
+    """The pass that normally renders only the listed pixels (reference visiting order in the interval form, then
+    the six-plane form) renders whole frames identical to the main kernel's and the oracle's: for a scene whose
+    trees the main kernel walks near side first, and for an LDS-resident one."""
+    b = Built(acr, orc, soup_data(acr, ntri, seed=6, edge=0.1 if ntri > 1000 else 0.3), mesh_depth=depth)
+    load(core, b)
+    w, h = 160, 96
+    ref = b.oracle.render(w, h, seed=8, frames=0, max_bounces=3)
+    img, pid, ht, st = render(core, w, h, seed=8, frames=0, max_bounces=3)
+    assert_same(img, pid, ht, st, ref)
+    core.set_traversal(list_pass=True)
+    try:
+        img2, pid2, ht2, st2 = render(core, w, h, seed=8, frames=0, max_bounces=3)
+    finally:
+        core.set_traversal()
+    assert st2.interval_traversal == 1 and st2.near_first == 0
+    assert st2.six_plane_pixels >= w * h   # every slot of the launch was listed
+    assert_same(img2, pid2, ht2, st2, ref)
+    assert (pid2 != 0xFFFFFFFF).mean() > 0.01
