@@ -30,6 +30,8 @@ namespace math
 		ACR_HD vec2() : x(0), y(0) {}
 		ACR_HD vec2(float a, float b) : x(a), y(b) {}
 	};
+	ACR_HD vec2 operator*(const vec2 &a, float s) { return vec2(a.x * s, a.y * s); } // type_vec2.inl, vec * scalar
+	ACR_HD vec2 operator-(const vec2 &a, const vec2 &b) { return vec2(a.x - b.x, a.y - b.y); }
 	struct u32vec2 { uint32_t x, y; };
 	struct u32vec3 { uint32_t x, y, z; };
 

@@ -119,3 +119,42 @@ def test_adaptive_assignment_in_the_render_loop(acr, orc, built):
         run(4, camera=cam)
     finally:
         r.close()
+
+
+def test_headless_application(acr, orc, tmp_path):
+    """The headless counterpart of the reference's application (src/application/application.cpp): a script of key
+    presses, a mouse drag and frames; the image it writes equals the oracle's frame from the camera the same
+    inputs produce (movSpeed 0.5, rotSpeed 1/1000, drag x negated; application.cpp:11-58)."""
+    import os
+    import subprocess
+    from conftest import soup_data
+    from oracle import OracleScene
+    app = os.path.join(os.path.dirname(os.path.abspath(acr.__file__)), "acr_app")
+    assert os.path.exists(app), "acr_app is built by cudaraytracer_amd/csrc/Makefile"
+    out = str(tmp_path / "frame.pfm")
+    w, h = 320, 200
+    run = subprocess.run([app, "--soup", "20000", "--mesh-depth", "12", "--size", f"{w}x{h}", "--seed", "7", "--bounces", "2",
+                          "--events", ". . w a . r30,-10; .", "--out", out], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert "4 frame(s) rendered" in run.stdout
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n" and f.readline() == f"{w} {h}\n".encode() and f.readline() == b"-1.0\n"
+        rgb = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]  # PFM rows run bottom-up
+
+    view, keep = soup_data(acr, 20000, seed=1, edge=0.1, extent=10.0).pack()
+    o = OracleScene(view, 6, 12)
+    try:
+        cam = orc.OrcCamera()
+        orc.lib().orc_scene_camera(o.h, C.byref(cam))
+        rot = np.float32(1.0) / np.float32(1000.0)  # the drag in float arithmetic, as the application computes it
+        drag = (float(-(np.float32(30) * rot)), float(np.float32(-10) * rot))
+        for pos, dr in (((0.0, 0.5), (0.0, 0.0)), ((-0.5, 0.0), (0.0, 0.0)), ((0.0, 0.0), drag)):
+            orc.lib().orc_move_camera(C.byref(cam), (C.c_float * 2)(*pos), (C.c_float * 2)(*dr))
+        ref = o.render(w, h, seed=7, frames=0, max_bounces=2, camera=cam)   # the last move restarted the accumulation
+        assert np.array_equal(rgb.view(np.uint32), np.ascontiguousarray(ref["screen"][..., :3]).view(np.uint32))
+        assert ref["counters"]["primary_hits"] > 100
+    finally:
+        o.close()
+
+    bad = subprocess.run([app, "/nonexistent/scene.blend"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "error" in bad.stderr
