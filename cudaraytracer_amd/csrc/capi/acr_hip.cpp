@@ -288,6 +288,7 @@ int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
 	    hipMalloc(reinterpret_cast<void **>(&ctx->counters), kCounterSlots * 4 * sizeof(unsigned long long)) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&ctx->redoCount), 2 * sizeof(uint32_t)) != hipSuccess ||
 	    hipMemset(ctx->redoCount, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+	    hipMemset(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long)) != hipSuccess ||
 	    hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess) {
 		acr_hip_destroy(ctx);
 		return ACR_ERR_HIP;
@@ -723,8 +724,11 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	// the interval form walks mesh trees that are not LDS-resident near side first, which needs leafOrderOk
 	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
+	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 	if (fast && plan.meshGlobLevels) {
-		const size_t slots = size_t(grid) * kBlock;
+		// one column per work-item of the larger of the two launches that use it (the list pass has its own fixed grid)
+		const size_t slots = size_t(grid > acr::dev::kRedoGrid ? grid : acr::dev::kRedoGrid) * kBlock;
 		if (slots >= (1ull << 32)) return fail(ctx, ACR_ERR_UNSUPPORTED, "launch too large for a mesh tree this deep");
 		const size_t need = slots * plan.meshGlobLevels * sizeof(float2);
 		if (ctx->meshGlobBytes < need) {
@@ -752,7 +756,6 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		p.redo_list = ctx->redoList;
 		p.redo_count = ctx->redoCount + ctx->redoParity;
 		p.redo_count_next = ctx->redoCount + (ctx->redoParity ^ 1u);
-		ctx->redoParity ^= 1u;
 	}
 
 	ctx->timed = f->collect_stats != 0;
@@ -764,7 +767,6 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	if (listOnly) {
 		// every slot of the launch goes onto the list; only the list pass runs
 		const uint32_t slots = grid * kBlock;
-		if (p.path_keys || p.tile_cycles) return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 		ACR_HIP_TRY(ctx, acr_dev_launch_iota(reinterpret_cast<int32_t *>(p.redo_list), slots, ctx->stream));
 		ctx->listAllCount = slots; // the copy below may read it after this call returned
 		ACR_HIP_TRY(ctx, hipMemcpyAsync(p.redo_count, &ctx->listAllCount, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -773,6 +775,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		measureBlocks = false;
 	}
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (fast ? 1 : 0), grid, plan.ldsBytes, ctx->stream));
+	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
+	if (fast) ctx->redoParity ^= 1u;
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
 	const uint32_t orderUsed = f->block_order_dev ? ACR_BLOCK_ORDER_CALLER : (p.block_order ? ACR_BLOCK_ORDER_MEASURED : ACR_BLOCK_ORDER_NATURAL);
 	if (ownOrder) {

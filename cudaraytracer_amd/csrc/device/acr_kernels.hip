@@ -44,6 +44,9 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../math/math.h"
 #include "../math/rng.h"
 #include "device_scene.h"
@@ -1354,11 +1357,32 @@ __global__ void __launch_bounds__(kBlock) scatterTilesKernel(const float4 *__res
 
 namespace
 {
+	// The dynamic-LDS limit of a kernel is raised once per (device, kernel) and only when a launch needs more than
+	// any earlier one: the attribute call costs a few microseconds of host time, which a 0.2 ms frame notices.
+	constexpr int kMaxDevices = 64;
 	template <class P>
 	hipError_t launchWithLds(void (*k)(const P), const P &p, uint32_t grid, size_t ldsBytes, hipStream_t stream)
 	{
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+		static std::mutex lock;
+		static std::unordered_map<const void *, size_t> granted[kMaxDevices];
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
+		const void *fn = reinterpret_cast<const void *>(k);
+		bool raise = true;
+		if (dev >= 0 && dev < kMaxDevices) {
+			std::lock_guard<std::mutex> g(lock);
+			auto it = granted[dev].find(fn);
+			raise = it == granted[dev].end() || it->second < ldsBytes;
+		}
+		if (raise) {
+			e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+			if (e != hipSuccess) return e;
+			if (dev >= 0 && dev < kMaxDevices) {
+				std::lock_guard<std::mutex> g(lock);
+				granted[dev][fn] = ldsBytes;
+			}
+		}
 		hipLaunchKernelGGL(k, dim3(grid), dim3(acr::dev::kBlock), ldsBytes, stream, p);
 		return hipGetLastError();
 	}
