@@ -114,6 +114,7 @@ HIP_SYMBOLS = {
     "acr_hip_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
     "acr_hip_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "acr_hip_render": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acr_hip_render_static": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]),
     "acr_hip_trace_rays": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, c_float_p, c_float_p, c_u8_p, c_float_p,
                                      c_u32_p, c_float_p, c_float_p]),
     "acr_hip_read_framebuffer": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),

@@ -168,7 +168,8 @@ class HipCore:
 
     def render(self, width, height, seed=0, frames=0, max_bounces=1, collect_stats=False, screen_dev=None,
                primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None,
-               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None):
+               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None, static=False):
+        """acr_hip_render; static=True calls acr_hip_render_static, the variant that allocates nothing."""
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
         f.collect_stats = int(collect_stats)  # False/True, or 2: counters accumulate over launches (ACR_STATS_ACCUMULATE)
@@ -182,7 +183,10 @@ class HipCore:
         f.tile_cycles_dev = tile_cycles_dev
         f.path_keys_dev = path_keys_dev
         f.block_order_dev = block_order_dev
-        self._check(self._lib.acr_hip_render(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render")
+        if static:
+            self._check(self._lib.acr_hip_render_static(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render_static")
+        else:
+            self._check(self._lib.acr_hip_render(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render")
 
     def sync(self):
         self._check(self._lib.acr_hip_sync(self._h), "acr_hip_sync")

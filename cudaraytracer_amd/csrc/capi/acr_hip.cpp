@@ -24,9 +24,23 @@ using acr::dev::RenderParams;
 using acr::dev::SceneHeader;
 using acr::dev::TraceParams;
 
+// Scratch of acr_hip_render_static: the list of pixel slots a launch hands to its list pass and the list's two
+// counters, in device memory that exists from the moment the library is loaded, so that the call allocates
+// nothing.  Each GPU holds its own copy; its address there comes from hipGetSymbolAddress (acr_hip_create).
+namespace
+{
+	struct StaticScratch
+	{
+		uint32_t redoCount[64]; // [0], [1]: the two counters; the rest keeps the list aligned
+		uint32_t redoList[ACR_STATIC_MAX_SLOTS];
+	};
+}
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
+
 struct acr_hip_ctx
 {
 	int device = 0;
+	StaticScratch *staticScratch = nullptr; // this device's copy of `scratch`
 	hipStream_t ownStream = nullptr;
 	hipStream_t stream = nullptr;
 	std::string error;
@@ -89,6 +103,7 @@ struct acr_hip_ctx
 	bool timed = false;
 	acr_stats stats{};
 	size_t lastSlots = 0; // pixel slots written by the last render
+	bool statsStatic = false; // the last render was acr_hip_render_static: its list counter is scratch's
 };
 
 namespace
@@ -294,6 +309,13 @@ int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
 		return ACR_ERR_HIP;
 	}
 	ctx->stream = ctx->ownStream;
+	// the device is current: this is its copy of the array
+	void *sp = nullptr;
+	if (hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp) {
+		acr_hip_destroy(ctx);
+		return ACR_ERR_HIP;
+	}
+	ctx->staticScratch = static_cast<StaticScratch *>(sp);
 	*out = ctx;
 	return ACR_OK;
 }
@@ -597,7 +619,11 @@ int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height)
 	return ACR_OK;
 }
 
-int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev)
+} // extern "C"
+
+// staticOnly: the launch may use nothing but what exists already -- the context's buffers, the caller's, and
+// this device's copy of `scratch`; whatever would need an allocation is refused.
+static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev, bool staticOnly)
 {
 	if (!ctx || !f) return fail(ctx, ACR_ERR_INVALID, "null argument");
 	if (!ctx->haveScene || !ctx->haveCamera) return fail(ctx, ACR_ERR_NO_SCENE, "render before scene and camera were set");
@@ -605,6 +631,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	if (f->max_bounces > ACR_MAX_BOUNCES) return fail(ctx, ACR_ERR_UNSUPPORTED, "max_bounces %u > %d", f->max_bounces, ACR_MAX_BOUNCES);
 	const bool tiled = f->num_tiles != 0;
 	const bool ownBuffers = screen_dev == nullptr;
+	if (staticOnly && (tiled || f->tile_rays_dev || f->tile_cycles_dev))
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "acr_hip_render_static renders whole frames only (a tile list needs a device copy)");
 	if (ownBuffers && (tiled || ctx->width != f->width || ctx->height != f->height))
 		return fail(ctx, ACR_ERR_INVALID, "context-owned framebuffer needs acr_hip_resize(width,height) and a full-frame render");
 	uint32_t tilesX = 0, grid = 0;
@@ -673,7 +701,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	// launch of a configuration; small launches do not fill the GPU and are left alone).
 	if (tiled && f->block_order_dev) return fail(ctx, ACR_ERR_INVALID, "block_order_dev needs a full-frame launch");
 	const uint32_t numBlocks = grid / kGroupsPerBlock;
-	const bool ownOrder = ctx->blockOrderEvery != 0 && !f->block_order_dev && numBlocks >= kMinBlocksForOrder;
+	// the context's own order lives in tables it allocates: not for the launch that may allocate nothing
+	const bool ownOrder = !staticOnly && ctx->blockOrderEvery != 0 && !f->block_order_dev && numBlocks >= kMinBlocksForOrder;
 	bool measureBlocks = false;
 	p.block_order = f->block_order_dev;
 	if (ownOrder) {
@@ -726,6 +755,12 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
 	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
+	if (staticOnly && fast && plan.meshGlobLevels)
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "acr_hip_render_static: this scene's mesh trees are %u levels deeper than the waiting-child column "
+		            "kept in LDS, and the part in global memory is allocated per launch size", plan.meshGlobLevels);
+	if (staticOnly && fast && size_t(grid) * kBlock > size_t(ACR_STATIC_MAX_SLOTS))
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "acr_hip_render_static: %zu pixel slots, the static list holds %u (frames up to 1920 x 1088)",
+		            size_t(grid) * kBlock, unsigned(ACR_STATIC_MAX_SLOTS));
 	if (fast && plan.meshGlobLevels) {
 		// one column per work-item of the larger of the two launches that use it (the list pass has its own fixed grid)
 		const size_t slots = size_t(grid > acr::dev::kRedoGrid ? grid : acr::dev::kRedoGrid) * kBlock;
@@ -743,7 +778,15 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 		p.mesh_glob_levels = plan.meshGlobLevels;
 		p.mesh_glob_stride = uint32_t(slots);
 	}
-	if (fast) {
+	if (fast && staticOnly) {
+		// Every call on this GPU shares the array and finds what the last one left: both counters start at zero
+		// here instead of relying on the previous list pass, which may have been another context's.
+		StaticScratch *sc = ctx->staticScratch;
+		ACR_HIP_TRY(ctx, hipMemsetAsync(sc->redoCount, 0, 2 * sizeof(uint32_t), ctx->stream));
+		p.redo_list = sc->redoList;
+		p.redo_count = sc->redoCount;
+		p.redo_count_next = sc->redoCount + 1;
+	} else if (fast) {
 		const size_t slots = size_t(grid) * kBlock;
 		if (ctx->redoCap < slots) {
 			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -776,7 +819,8 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	}
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (fast ? 1 : 0), grid, plan.ldsBytes, ctx->stream));
 	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
-	if (fast) ctx->redoParity ^= 1u;
+	if (fast && !staticOnly) ctx->redoParity ^= 1u;
+	ctx->statsStatic = staticOnly;
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
 	const uint32_t orderUsed = f->block_order_dev ? ACR_BLOCK_ORDER_CALLER : (p.block_order ? ACR_BLOCK_ORDER_MEASURED : ACR_BLOCK_ORDER_NATURAL);
 	if (ownOrder) {
@@ -799,6 +843,18 @@ int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint3
 	ctx->stats.near_first = (fast && !listOnly && plan.ldsMode != 2) ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
+}
+
+extern "C" {
+
+int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev)
+{
+	return renderImpl(ctx, f, screen_dev, primid_dev, hit_t_dev, false);
+}
+
+int acr_hip_render_static(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev)
+{
+	return renderImpl(ctx, f, screen_dev, primid_dev, hit_t_dev, true);
 }
 
 int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const float *dirs, const float *tmax,
@@ -898,7 +954,8 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 		if (ctx->stats.interval_traversal) {
 			// the counter of the last frame is the one the next frame will NOT use; it is zeroed one frame later
 			uint32_t n = 0;
-			ACR_HIP_TRY(ctx, hipMemcpy(&n, ctx->redoCount + (ctx->redoParity ^ 1u), sizeof(n), hipMemcpyDeviceToHost));
+			const uint32_t *counter = ctx->statsStatic ? ctx->staticScratch->redoCount : ctx->redoCount + (ctx->redoParity ^ 1u);
+			ACR_HIP_TRY(ctx, hipMemcpy(&n, counter, sizeof(n), hipMemcpyDeviceToHost));
 			ctx->stats.six_plane_pixels = n;
 		}
 	}

@@ -248,6 +248,21 @@ int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height);
  *                primary hit (scene.cu:431) or FLT_MAX; NULL = context-owned */
 int acr_hip_render(acr_hip_ctx *ctx, const acr_frame *frame, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev);
 
+/* acr_hip_render for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (its renderer allocates everything
+ * once, in Renderer::Renderer).  Same arguments, same kernels and bit-identical frames; the call itself
+ * allocates and frees nothing.  The list of pixel slots the launch hands to its list pass, which acr_hip_render
+ * keeps in a buffer sized per launch, lives in a fixed array in the library's device image
+ * (4 * ACR_STATIC_MAX_SLOTS + 256 bytes per GPU, held until the process ends).  Limits, each refused with
+ * ACR_ERR_UNSUPPORTED and a message: whole frames only (no tile list, no per-tile costs); at most
+ * ACR_STATIC_MAX_SLOTS pixel slots, i.e. ceil(width / 16) * ceil(height / 16) * 256 (1920 x 1080 fits); no scene
+ * whose mesh trees are too deep for the LDS part of the waiting-child column (about 14 levels); the context's
+ * measured block order is not used (natural order, or acr_frame::block_order_dev).  The framebuffer is the
+ * caller's, or the context's after acr_hip_resize.  All contexts on one GPU share the array: calls that
+ * overlap in time on one GPU (two contexts, or two streams) race on it and must be serialised by the caller. */
+#define ACR_STATIC_MAX_SLOTS (1u << 21)
+int acr_hip_render_static(acr_hip_ctx *ctx, const acr_frame *frame, void *screen_dev, uint32_t *primid_dev, float *hit_t_dev);
+
 /* Closest-hit queries for caller-supplied rays: Scene::intersect (scene.cu:204-207)
  * with info.t preset to tmax[i].  Host arrays in and out; synchronous. */
 int acr_hip_trace_rays(acr_hip_ctx *ctx, uint32_t n, const float *origins, const float *dirs, const float *tmax,
