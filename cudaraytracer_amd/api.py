@@ -150,11 +150,11 @@ class HipCore:
     def use_own_stream(self):
         self._check(self._lib.acr_hip_use_own_stream(self._h), "acr_hip_use_own_stream")
 
-    def set_traversal(self, six_plane_only=False, list_pass=False):
+    def set_traversal(self, six_plane_only=False, list_pass=False, nested=False):
         """Default: interval form of the slab test wherever it is provably identical.  six_plane_only: the
         six-plane form as written in the reference for every ray.  list_pass: every pixel through the pass that
         normally renders only the listed ones (reference visiting order; slow, for tests)."""
-        mode = 2 if list_pass else (1 if six_plane_only else 0)
+        mode = 3 if nested else (2 if list_pass else (1 if six_plane_only else 0))
         self._check(self._lib.acr_hip_set_traversal(self._h, mode), "acr_hip_set_traversal")
 
     def set_block_order(self, every):

@@ -227,13 +227,16 @@ namespace
 		uint32_t stackSlot;
 		size_t ldsBytes;
 		uint32_t cstackOff;       // floats from the first column to the direct-term columns
+		uint32_t waveOff;         // floats from the first column to the per-wave task tables; 0: the launch has none
 		uint32_t meshGlobLevels;  // top levels of the mesh tree's waiting-child column kept in global memory
 	};
 
 	// Decides how much of the scene a workgroup stages into LDS and how the per-lane columns are laid out.
 	// splitDeepColumns: false for traceKernel, which keeps every level of the waiting-child column in LDS and
 	// needs room for the six-plane form's columns next to them.
-	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns)
+	// waveTasks: also lay out the per-wave task tables of the wave-cooperative kernel, if the scene then still fits
+	// LDS whole (plan.waveOff != 0 says it did).
+	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false)
 	{
 		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
 		// six-plane traversal's undo column (the list pass runs in the same LDS block).  A deep mesh tree keeps
@@ -253,6 +256,17 @@ namespace
 		const size_t columnFloats = (splitDeepColumns ? (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) : intervalFloats + sixPlaneFloats) * kBlock;
 		const size_t stackBytes = (columnFloats + size_t(3) * colorLevels * kBlock) * 4;
 		LaunchPlan p;
+		p.waveOff = 0;
+		const size_t waveBytes = size_t(kBlock / 64) * acr::dev::waveLdsWords(h.num_objects) * 4;
+		if (waveTasks && h.num_objects <= acr::dev::kWaveMaxObjects && size_t(h.total_slots) * 16 + stackBytes + waveBytes <= kLdsBudget) {
+			p.ldsMode = 2;
+			p.stackSlot = h.total_slots;
+			p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes + waveBytes;
+			p.cstackOff = uint32_t(columnFloats);
+			p.waveOff = uint32_t(stackBytes / 4);
+			p.meshGlobLevels = 0;
+			return p;
+		}
 		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {
 			p.ldsMode = 2;
 			p.stackSlot = h.total_slots;
@@ -375,7 +389,7 @@ int acr_hip_set_block_order(acr_hip_ctx *ctx, uint32_t every)
 
 int acr_hip_set_traversal(acr_hip_ctx *ctx, int mode)
 {
-	if (!ctx || (mode != ACR_TRAVERSAL_AUTO && mode != ACR_TRAVERSAL_SIX_PLANE && mode != ACR_TRAVERSAL_LIST_PASS))
+	if (!ctx || (mode != ACR_TRAVERSAL_AUTO && mode != ACR_TRAVERSAL_SIX_PLANE && mode != ACR_TRAVERSAL_LIST_PASS && mode != ACR_TRAVERSAL_NESTED))
 		return fail(ctx, ACR_ERR_INVALID, "unknown traversal mode");
 	ctx->traversalMode = mode;
 	return ACR_OK;
@@ -747,12 +761,17 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	if (p.tile_rays) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_rays, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 	if (p.tile_cycles) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_cycles, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
 
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true);
+	// Frames with bounces on scenes that fit LDS are rendered by the wave-cooperative kernel (object tests as tasks
+	// compacted across the wavefront), if its tables fit as well.
+	const bool wantWave = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && f->max_bounces > 1 && !f->path_keys_dev;
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
+	p.lds_wave_off = plan.waveOff;
 	// the interval form walks mesh trees that are not LDS-resident near side first, which needs leafOrderOk
 	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
+	const bool waveKernel = fast && plan.waveOff != 0;
 	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 	if (staticOnly && fast && plan.meshGlobLevels)
@@ -817,7 +836,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		p.block_cost = nullptr;
 		measureBlocks = false;
 	}
-	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (fast ? 1 : 0), grid, plan.ldsBytes, ctx->stream));
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (fast ? 1 : 0)), grid, plan.ldsBytes, ctx->stream));
 	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
 	if (fast && !staticOnly) ctx->redoParity ^= 1u;
 	ctx->statsStatic = staticOnly;
@@ -841,6 +860,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	ctx->stats.grid_blocks = grid;
 	ctx->stats.interval_traversal = fast ? 1u : 0u;
 	ctx->stats.near_first = (fast && !listOnly && plan.ldsMode != 2) ? 1u : 0u;
+	ctx->stats.wave_tasks = waveKernel ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }

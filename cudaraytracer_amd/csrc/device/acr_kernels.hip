@@ -72,6 +72,11 @@ static_assert(ACR_BLOCK_SLOTS % ACR_BLOCK == 0 && ACR_BLOCK % 64 == 0, "a block 
 #define ACR_RENDER_WAVES_HBM 5
 #endif
 
+// waves per SIMD the wave-cooperative kernel is compiled for
+#ifndef ACR_WAVE_KERNEL_WAVES
+#define ACR_WAVE_KERNEL_WAVES 4
+#endif
+
 extern __shared__ uint4 g_lds[];
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
@@ -674,14 +679,15 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // primary and shadow rays, which are normalised; bounce directions are not
 // (math.h:188-192), so the caller measures them.
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
-template <bool FULL, bool FAST, class Mem>
+// PREFILTER = false: the caller has made the world-box test already (saWorld and tLimit are not read).
+template <bool FULL, bool FAST, bool PREFILTER = true, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
                                                 WorldHit &info, const Columns &col, bool &bail, float tLimit)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
 	const uint32_t flags = b0.w;
-	if (flags & kObjPrefilter) {
+	if (PREFILTER && (flags & kObjPrefilter)) {
 		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
 		if constexpr (FAST) {
 			const Interval wb = boxInterval(saWorld, wmin, wmax);
@@ -1147,6 +1153,473 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 	return res;
 }
 
+
+// ---- object tests as tasks compacted across the wavefront ----------------------------------------------------
+//
+// With incoherent rays (everything after the first bounce) the lanes of a wave reach the expensive part of a
+// traversal -- Object::intersect past its box test: two matrix transforms, four divides, a square root, the mesh
+// tree, the triangles -- at different moments of their walks through the tree over objects, and the wave runs
+// that code once for every such moment with a few lanes live.  What an object test returns does not depend on
+// the walk: scene.cu:407-440 starts from tmpInfo.t = FLT_MAX and compares with info.t only at its end
+// (scene.cu:432).  So a wave traces its 64 rays in three steps:
+//   A  every lane tests its ray against the grown world box of every object (the test objectIntersect makes
+//      first; a ray that fails it would get `false` and an untouched info from the reference, see there).
+//      The lanes that pass object k are counted with one ballot, and (lane, k) goes to a task list in LDS at
+//      offset[k] + rank within the ballot: the list comes out compact and sorted by object.
+//   B  lane j takes tasks j, j + 64, ...: it fetches that ray from the wave's ray table, runs the object test
+//      from FLT_MAX and stores `intersected` and the world distance.  Lanes whose own path has ended, or whose
+//      ray has no candidates, work on other lanes' tasks; neighbouring lanes test the same object.
+//   C  every lane walks the tree over objects for its own ray exactly as bih.h:209-299 does -- same slab
+//      tests against the current info.t, same order -- and where the reference calls Object::intersect it
+//      looks the result up: info is replaced iff t < info.t (scene.cu:432), `intersected` accumulates.
+// For a closest-hit query the winning object is tested once more for position, normal and primitive id.
+// A task list holds kWaveTaskSlots entries per lane on average; a candidate that does not fit is tested by its
+// own lane during step C, as the nested kernel does.
+
+#ifdef ACR_WAVE_DEBUG
+// experiment builds only: wave traces, rays, tasks, tasks beyond the list, rounds of step B
+__device__ unsigned long long g_waveDebug[16];
+#define g_dbgAcc wl.dbg
+#endif
+constexpr uint32_t kTaskHit = 0x8000u, kTaskBail = 0x4000u;
+
+// LDS of one wave for the steps above; offsets in 4-byte words from the wave's base
+struct WaveLds
+{
+	float *results;     // [kWaveCap] world distance of each task's hit (FLT_MAX: info would not be replaced)
+	uint16_t *queue;    // [kWaveCap] lane | object << 6, then | kTaskHit | kTaskBail
+	uint32_t *ballotLo, *ballotHi; // [num_objects] lanes that are candidates of object k
+	uint32_t *offset;   // [num_objects] first task of object k
+#ifdef ACR_WAVE_DEBUG
+	uint64_t *dbg;      // per-lane accumulators; lane 0's are added to g_waveDebug when the wave ends
+#endif
+};
+__device__ __forceinline__ void waveSync()
+{
+	// the lanes of a wave exchange data through LDS: keep the compiler from moving LDS accesses across, and make
+	// the accesses issued so far complete (LDS serves a wave's instructions in order)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Scene::intersect for the rays of a wave, called by all 64 lanes together (uniform control flow).  `active`: this
+// lane has a ray.  SHADOW: returns the occlusion flag of scene.cu:226,266 for a ray whose info.t starts at lightT;
+// otherwise returns `intersected` and fills info (position, normal, material, prim of the closest hit).
+template <bool SHADOW, class Mem>
+__device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHeader &sc, const WaveLds &wl, bool active, const Ray &r, WorldHit &info,
+                                                   float lightT, const Columns &col, bool &bail)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	SlabArgs sa;
+	sa.o = vec3(0, 0, 0);
+	sa.invD = vec3(1, 1, 1);
+	bool part = active;
+	if (active) {
+		sa.init(r);
+		if (!rayIsFinite(sa)) {
+			bail = true;
+			part = false;
+		}
+	}
+#ifdef ACR_WAVE_DEBUG
+	uint64_t dbgT0 = __builtin_readcyclecounter();
+#define ACR_DBG_PHASE(n) { const uint64_t now_ = __builtin_readcyclecounter(); g_dbgAcc[n] += now_ - dbgT0; dbgT0 = now_; }
+#else
+#define ACR_DBG_PHASE(n)
+#endif
+	waveSync(); // the previous call's step C has read the tables
+	// step A.  The object records are the same for every lane: read through the global pointer with a uniform
+	// index they come in over the scalar cache, not out of LDS.  Lane k keeps object k's ballot and list offset
+	// and all of them are stored at once after the loop.
+	const float tLimit = SHADOW ? lightT : FLT_MAX; // info.t as the traversal starts; it only shrinks afterwards
+	uint32_t total = 0;
+	uint32_t keepLo = 0, keepHi = 0, keepOff = 0;
+	uint64_t candMask = 0;
+	for (uint32_t k = 0; k < sc.num_objects; k++) {
+		const uint32_t os = sc.off_objects + k * kObjectSlots;
+		const uint4 b0 = mem.g[os], b1 = mem.g[os + 1];
+		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
+		const Interval wb = boxInterval(sa, wmin, wmax);
+		const bool cand = part && (!(b0.w & kObjPrefilter) || intervalHit(wb.tmin, wb.tmax, tLimit));
+		const uint64_t bal = __ballot(cand);
+		const bool mine = lane == k;
+		keepLo = mine ? uint32_t(bal) : keepLo;
+		keepHi = mine ? uint32_t(bal >> 32) : keepHi;
+		keepOff = mine ? total : keepOff;
+		if (cand) {
+			candMask |= 1ull << k;
+			const uint32_t slot = total + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u));
+			if (slot < kWaveCap) wl.queue[slot] = uint16_t(lane | (k << 6));
+		}
+		total += uint32_t(__popcll(bal));
+	}
+	if (lane < sc.num_objects) {
+		wl.ballotLo[lane] = keepLo;
+		wl.ballotHi[lane] = keepHi;
+		wl.offset[lane] = keepOff;
+	}
+	const uint32_t queued = total < kWaveCap ? total : kWaveCap;
+#ifdef ACR_WAVE_DEBUG
+	{
+		const uint64_t pb = __ballot(part);
+		g_dbgAcc[0] += 1;
+		g_dbgAcc[1] += __popcll(pb);
+		g_dbgAcc[2] += total;
+		g_dbgAcc[3] += total - queued;
+		g_dbgAcc[4] += (queued + 63) / 64;
+	}
+#endif
+	waveSync();
+	ACR_DBG_PHASE(5)
+	// step B: the ray of task (lane rl, object obj) comes straight out of lane rl's registers
+	for (uint32_t base = 0; base < queued; base += 64u) {
+		const uint32_t task = base + lane;
+		const bool valid = task < queued;
+		const uint32_t e = valid ? uint32_t(wl.queue[task]) : 0u;
+		const int rl = int(e & 63u);
+		Ray tr;
+		tr.o = vec3(__shfl(r.o.x, rl, 64), __shfl(r.o.y, rl, 64), __shfl(r.o.z, rl, 64));
+		tr.d = vec3(__shfl(r.d.x, rl, 64), __shfl(r.d.y, rl, 64), __shfl(r.d.z, rl, 64));
+		if (valid) {
+			WorldHit th;
+			th.t = FLT_MAX;
+			bool tb = false;
+			const bool hit = objectIntersect<false, true, false>(mem, sc, e >> 6, tr, sa, th, col, tb, FLT_MAX);
+			wl.results[task] = th.t;
+			wl.queue[task] = uint16_t(e | (hit ? kTaskHit : 0u) | (tb ? kTaskBail : 0u));
+		}
+	}
+	waveSync();
+	ACR_DBG_PHASE(6)
+	// step C
+	bool intersected = false, occluded = false;
+	uint32_t best = 0;
+	if (part) {
+		const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
+		auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
+		auto leaf = [&](uint32_t start, uint32_t end) {
+			for (uint32_t i = start; i < end; i++) {
+				if (!((candMask >> i) & 1ull))
+					continue; // the ray misses the object's grown box: Object::intersect returns false, info untouched
+				const uint32_t lo = wl.ballotLo[i], hi = wl.ballotHi[i];
+				const uint32_t slot = wl.offset[i] + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+				bool hit;
+				float t;
+				if (slot < kWaveCap) {
+					const uint32_t e = wl.queue[slot];
+					hit = (e & kTaskHit) != 0;
+					if (e & kTaskBail) bail = true;
+					t = wl.results[slot];
+				} else {
+					WorldHit th;
+					th.t = FLT_MAX;
+					hit = objectIntersect<false, true, false>(mem, sc, i, r, sa, th, col, bail, FLT_MAX);
+					t = th.t;
+				}
+				if (bail) return true;
+				intersected |= hit;
+				if (hit && t < info.t) { // scene.cu:432
+					info.t = t;
+					best = i;
+				}
+				if constexpr (SHADOW) {
+					if (info.t + epsilon() < lightT) {
+						occluded = true;
+						return true;
+					}
+				}
+			}
+			return false;
+		};
+		auto tcur = [&]() { return info.t; };
+		const LevelColumn lc = {reinterpret_cast<float2 *>(col.scene), nullptr, 0u, 0u};
+		bihTraverseFast(loadNode, sa, boxInterval(sa, smin, smax), lc, leaf, tcur);
+	}
+	ACR_DBG_PHASE(7)
+	if constexpr (SHADOW) {
+		return occluded;
+	} else {
+		// the closest hit once more, this time for everything a shaded hit needs
+		if (part && !bail && intersected && info.t < FLT_MAX) {
+			WorldHit full;
+			full.t = FLT_MAX;
+			full.material = 0;
+			full.prim = 0xFFFFFFFFu;
+			full.position = vec3(0, 0, 0);
+			full.normal = vec3(0, 0, 0);
+			objectIntersect<true, true, false>(mem, sc, best, r, sa, full, col, bail, FLT_MAX);
+			info = full;
+		}
+		ACR_DBG_PHASE(8)
+		return intersected;
+	}
+}
+
+// scatterTrace (renderer.cu:326-388) for the 64 pixel slots of a wave together: renderSlot with every
+// Scene::intersect made by the wave as a whole (waveSceneIntersect), hence in uniform control flow: all lanes
+// walk the bounce levels and the lights in step, each with its own `alive` flag.
+template <class Mem>
+__device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
+{
+	const uint32_t maxBounces = p.max_bounces;
+	const SceneHeader &sc = p.scene;
+	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
+	Columns col;
+	col.scene = ldsF + 2 * threadIdx.x;
+	col.mesh = col.scene + 2 * sc.scene_depth * kBlock;
+	col.meshGlobLevels = 0u;
+	col.meshGlobStride = 0u;
+	col.meshGlob = nullptr;
+	float *cstack = ldsF + p.lds_cstack_off + threadIdx.x;
+	WaveLds wl;
+	{
+		float *base = ldsF + p.lds_wave_off + (threadIdx.x >> 6) * waveLdsWords(sc.num_objects);
+		wl.results = base;
+		wl.queue = reinterpret_cast<uint16_t *>(wl.results + kWaveCap);
+		wl.ballotLo = reinterpret_cast<uint32_t *>(wl.results + kWaveCap + kWaveCap / 2);
+		wl.ballotHi = wl.ballotLo + sc.num_objects;
+		wl.offset = wl.ballotHi + sc.num_objects;
+	}
+#ifdef ACR_WAVE_DEBUG
+	uint64_t dbgAcc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	wl.dbg = dbgAcc;
+	struct DbgFlush
+	{
+		uint64_t *a;
+		__device__ ~DbgFlush()
+		{
+			if ((threadIdx.x & 63u) == 0)
+				for (int k = 0; k < 9; k++) atomicAdd(&g_waveDebug[k], (unsigned long long)a[k]);
+		}
+	} dbgFlush{dbgAcc};
+#endif
+
+	const uint32_t lane = vtid & 63u, wave = vtid >> 6;
+	const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3), ly = (lane >> 3) + ((wave >> 1) << 3);
+	SlotResult res;
+	res.tileNo = 0;
+	res.bail = false;
+	res.cnt = {0, 0, 0};
+	uint32_t oldx, oldy;
+	size_t outSlot = 0;
+	const bool tiled = p.num_tiles != 0;
+	if (tiled) {
+		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
+		const uint32_t tileNo = vblock / bpt, sub = vblock % bpt;
+		const uint32_t tile = p.tile_ids[tileNo];
+		res.tileNo = tileNo;
+		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
+		oldx = (tile % p.tiles_x) * p.tile_w + inx;
+		oldy = (tile / p.tiles_x) * p.tile_h + iny;
+		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
+	} else {
+		oldx = (vblock % p.blocks_x) * 16u + lx;
+		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
+	}
+	Counters &cnt = res.cnt;
+	res.active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
+	bool alive = res.active;
+
+	int index = 0, x = 0, y = 0;
+	if (alive) {
+		const int width = int(p.width);
+		const int oldIndex = int(oldx) + width * int(oldy);
+		if (p.frames == 0 || !p.pixel_values) { // renderer.cu:344-352
+			if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
+			index = oldIndex;
+			x = int(oldx);
+			y = int(oldy);
+		} else {
+			index = p.pixel_values[oldIndex];
+			x = index % width;
+			y = index / width;
+		}
+		if (!tiled) outSlot = size_t(index);
+	}
+	RandState state;
+	randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
+	const float i = 2.0f * (float(x) + randUniform(state)) * p.inv_width - 1.0f;
+	const float j = 2.0f * (float(y) + randUniform(state)) * p.inv_height - 1.0f;
+	Ray r;
+	r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+	r.d = getPixelDir(p, i, -j);
+
+	vec3 source(1, 1, 1);
+	vec4 tail(0, 0, 0, 1);
+	uint32_t kept = 0; // direct terms of this lane waiting in cstack
+	bool bail = false;
+	if (alive) {
+		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
+		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
+	}
+	for (uint32_t level = 0; level < maxBounces; level++) { // rayColor<0> (renderer.cu:318-324) is the initial `tail`
+		if (!__any(alive))
+			break;
+		WorldHit info;
+		info.t = FLT_MAX;
+		info.material = 0;
+		info.prim = 0xFFFFFFFFu;
+		info.position = vec3(0, 0, 0);
+		info.normal = vec3(0, 0, 0);
+		if (alive && level > 0) cnt.bounce++;
+		const bool hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
+		if (alive && (bail || !hit)) alive = false; // a miss: renderer.cu:315
+		if (alive && level == 0) {
+			if (p.primid) p.primid[outSlot] = info.prim;
+			if (p.hit_t) p.hit_t[outSlot] = info.t;
+			cnt.primaryHits++;
+		}
+		// direct illum (renderer.cu:247-248): Scene::lightPoint (scene.cu:273-292), the lights in step across the wave
+		vec3 lightSum(0, 0, 0);
+		for (uint32_t li = 0; li < sc.num_lights; li++) {
+			vec3 dir(0, 0, 1), c(0, 0, 0);
+			float t = 0.0f;
+			bool trace = false;
+			if (alive) {
+				const Light l = loadLight(mem, sc, li);
+				trace = true;
+				if (l.type == 0u) { // pointLightAccum, scene.cu:209-231
+					dir = (l.position + 0.5f * randNorm(state)) - info.position;
+					t = length(dir);
+					dir = normalize(dir);
+					const float cosTheta = max(dot(dir, info.normal), 0.0f);
+					c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * t) * t) * l.diffuse;
+					if (length(c) < epsilon()) trace = false;
+				} else { // spotLightAccum, scene.cu:234-271
+					dir = l.position - info.position;
+					t = length(dir);
+					dir = normalize(dir);
+					const float cosTheta = max(dot(dir, info.normal), 0.0f);
+					const float cosLight = dot(-dir, normalize(l.direction));
+					const float lightTheta = acosf(cosLight);
+					const float inner = l.outerCone - 1.57079632679f;
+					const float outer = l.innerCone;
+					const float falloff_distance = outer - inner;
+					if (fabsf(lightTheta) >= outer / 2.0f) {
+						c = vec3(0, 0, 0);
+						trace = false;
+					} else {
+						c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * t) * t) * l.diffuse;
+						if (length(c) < epsilon()) {
+							trace = false;
+						} else {
+							const float val = (outer / 2.0f - fabsf(lightTheta));
+							const float falloff = val / (falloff_distance / 2.0f);
+							if (double(fabsf(lightTheta)) >= double(inner) / 2.0)
+								c *= falloff;
+						}
+					}
+				}
+				if (trace) cnt.shadow++;
+			}
+			Ray sr;
+			sr.o = info.position;
+			sr.d = dir;
+			WorldHit sh;
+			sh.t = t;
+			if (waveSceneIntersect<true>(mem, sc, wl, trace, sr, sh, t, col, bail))
+				c = vec3(0, 0, 0);
+			if (alive && bail) alive = false;
+			if (alive) lightSum += c;
+		}
+		if (alive) {
+			const uint32_t msl = sc.off_materials + info.material * kMaterialSlots;
+			const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
+			const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
+			const float refractiveIndex = asF(m0.w);
+			const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
+			const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
+			const vec3 c = ambient + diffuse * lightSum;
+			// indirect illum; nSource is uninitialised in the reference's translucent branch (renderer.cu:251,286-311):
+			// defined as `source` here
+			vec3 nSource = source;
+			Ray nr;
+			nr.o = info.position;
+			nr.d = vec3(0, 0, 0);
+			const bool last = level + 1 == maxBounces; // the next level returns (0,0,0,1) whatever the ray
+			bool absorbed = false;
+			if (refractiveIndex == 0) {
+				const vec3 cd = source * diffuse;
+				const vec3 cs = source * specular;
+				const float Pd = compMax(cd) / compMax(source);
+				const float Ps = compMax(cs) / compMax(source);
+				const float P = randUniform(state);
+				if (P < Pd) {
+					if (!last) {
+						nSource = cd * (1 / Pd);
+						nr.d = randomHemi(info.normal, state);
+					}
+				} else if (P < Pd + Ps) {
+					if (!last) {
+						nSource = cs * (1 / Ps);
+						nr.d = reflect(r.d, info.normal);
+					}
+				} else {
+					absorbed = true; // renderer.cu:282
+				}
+			} else if (!last) {
+				float n1, n2;
+				vec3 norm = info.normal;
+				if (dot(r.d, norm) < 0) {
+					n1 = refractiveIndex;
+					n2 = 1;
+				} else {
+					n1 = 1;
+					n2 = refractiveIndex;
+					norm *= -1.0f;
+				}
+				const float R = rSchlick2(r.d, norm, n1, n2);
+				if (randUniform(state) >= R)
+					nr.d = refract(r.d, norm, n1 / n2);
+				else
+					nr.d = reflect(r.d, norm);
+			}
+			if (absorbed) {
+				tail = vec4(c, 1);
+				alive = false;
+			} else if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
+				tail = vec4(c, 1) + vec4(0, 0, 0, 1);
+				alive = false;
+			} else {
+				// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
+				cstack[(3 * level + 0) * kBlock] = c.x;
+				cstack[(3 * level + 1) * kBlock] = c.y;
+				cstack[(3 * level + 2) * kBlock] = c.z;
+				kept = level + 1;
+				r = nr;
+				source = nSource;
+			}
+		}
+	}
+	if (!res.active)
+		return res;
+	if (bail) {
+		// nothing of this pixel is kept: the six-plane pass renders it from the start
+		res.bail = true;
+		res.cnt = {0, 0, 0};
+		return res;
+	}
+	vec4 contribution = tail;
+	while (kept > 0) {
+		kept--;
+		const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
+		contribution = cl + contribution;
+	}
+	// average (renderer.cu:375-387)
+	float4 *px = p.screen + outSlot;
+	if (p.frames > 0) {
+		const float4 old = *px;
+		vec4 s(old.x, old.y, old.z, old.w);
+		s = s * (float(p.frames) / float(p.frames + 1));
+		s = s + (contribution / float(p.frames + 1));
+		*px = make_float4(s.x, s.y, s.z, s.w);
+	} else {
+		*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
+	}
+	return res;
+}
+
 // Adds one wave's ray counts to the per-tile and per-launch counters.
 __device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotResult &res, uint32_t vblock)
 {
@@ -1196,6 +1669,37 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 			const uint32_t at = atomicAdd(p.redo_count, 1u);
 			p.redo_list[at] = vblock * kSlots + vtid;
 		}
+	}
+	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
+		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	if (p.block_cost && (threadIdx.x & 63u) == 0)
+		atomicAdd(&p.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	reportCounts(p, res, vblock);
+}
+
+// renderKernel for scenes resident in LDS and frames with bounces: the waves trace their rays together
+// (renderSlotWave).  Same grid, same block order, same list pass afterwards.
+__global__ void __launch_bounds__(kBlock, ACR_WAVE_KERNEL_WAVES) renderWaveKernel(const RenderParams p)
+{
+	const SceneHeader &sc = p.scene;
+	SceneMem<true, true> mem;
+	mem.g = p.blob;
+	stageScene(p.blob, sc.total_slots);
+	const bool tiled = p.num_tiles != 0;
+	const uint64_t clock0 = ((tiled && p.tile_cycles) || p.block_cost) ? __builtin_readcyclecounter() : 0;
+	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
+	const uint32_t gblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
+	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
+#ifdef ACR_WAVE_DEBUG
+	const uint64_t dbgK0 = __builtin_readcyclecounter();
+#endif
+	const SlotResult res = renderSlotWave(p, mem, vblock, vtid);
+#ifdef ACR_WAVE_DEBUG
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&g_waveDebug[9], (unsigned long long)(__builtin_readcyclecounter() - dbgK0));
+#endif
+	if (res.bail) {
+		const uint32_t at = atomicAdd(p.redo_count, 1u);
+		p.redo_list[at] = vblock * kSlots + vtid;
 	}
 	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
 		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
@@ -1389,7 +1893,7 @@ namespace
 } // namespace
 
 // fast == 1: interval traversal for the whole grid, then the list pass over whatever it handed back
-// (p->redo_* must be set).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
+// (p->redo_* must be set).  fast == 3: the same with the wave-cooperative kernel (scene whole in LDS, no keys).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
 // traversal for the whole grid.  p->path_keys selects the
 // variants that also record the per-pixel traversal-path key.
 template <bool KEYS>
@@ -1405,6 +1909,7 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 	if (fast == 2) return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream); // the caller has listed every slot
 	K k = ldsMode == 2 ? renderKernel<true, true, true, KEYS> : (ldsMode == 1 ? renderKernel<true, false, true, KEYS> : renderKernel<false, false, true, KEYS>);
 	if constexpr (!KEYS) {
+		if (fast == 3) k = renderWaveKernel; // ldsMode 2 only
 		if (p->max_bounces == 1)
 			k = ldsMode == 2 ? renderKernel<true, true, true, false, true> : (ldsMode == 1 ? renderKernel<true, false, true, false, true> : renderKernel<false, false, true, false, true>);
 	}
@@ -1455,3 +1960,13 @@ extern "C" hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint
 	                   tilesX, width, height, static_cast<float4 *>(frame));
 	return hipGetLastError();
 }
+
+#ifdef ACR_WAVE_DEBUG
+extern "C" int acr_dev_wave_debug(unsigned long long *out, int reset)
+{
+	unsigned long long z[16] = {0};
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(acr::dev::g_waveDebug), sizeof(z)) != hipSuccess) return 1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(acr::dev::g_waveDebug), z, sizeof(z)) != hipSuccess) return 1;
+	return 0;
+}
+#endif

@@ -48,6 +48,7 @@ namespace dev
 		uint32_t *tile_cycles;        // device [num_tiles] or null
 		uint32_t lds_stack_slot;    // first LDS slot after the staged scene
 		uint32_t lds_cstack_off;    // floats from there to the per-bounce-level direct-term columns
+		uint32_t lds_wave_off;      // floats from there to the per-wave task tables of the wave-cooperative kernel
 		// Interval traversal of deep mesh trees: the top mesh_glob_levels levels of the waiting-child column live in
 		// global memory (mesh_glob[level * mesh_glob_stride + slot], slot = workgroup * ACR_BLOCK + work-item), the
 		// levels below them in LDS.  0 levels for trees that fit LDS whole.
@@ -62,6 +63,17 @@ namespace dev
 		uint32_t *block_cost;        // device [blocks of the launch] or null: wave clock ticks spent per block, summed over its waves
 		const uint32_t *block_order; // device [blocks of the frame] or null: which block of 16 x 16 pixels the k-th block of the grid renders (full-frame launches)
 	};
+
+	// Wave-cooperative kernel: a wave's task list holds kWaveCap object tests (ACR_WAVE_TASK_SLOTS per lane), and a
+	// wave owns waveLdsWords(num_objects) 4-byte words of LDS: the tasks' results (kWaveCap), the task list
+	// (kWaveCap 16-bit entries) and per object two ballot halves and a list offset.  Lane k of a wave collects
+	// what belongs to object k, hence at most 64 objects.
+#ifndef ACR_WAVE_TASK_SLOTS
+#define ACR_WAVE_TASK_SLOTS 2
+#endif
+	constexpr uint32_t kWaveCap = 64u * ACR_WAVE_TASK_SLOTS;
+	constexpr uint32_t kWaveMaxObjects = 64;
+	constexpr uint32_t waveLdsWords(uint32_t numObjects) { return kWaveCap + kWaveCap / 2u + 3u * numObjects; }
 
 	// workgroups of the list pass
 	constexpr uint32_t kRedoGrid = 64;

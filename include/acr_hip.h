@@ -50,6 +50,8 @@ extern "C" {
 #define ACR_TRAVERSAL_SIX_PLANE 1  /* the slab test exactly as written (geometry.h:44-76) for every ray */
 #define ACR_TRAVERSAL_LIST_PASS 2  /* every pixel through the pass that normally renders only the listed ones: the interval form in the
                                      reference's visiting order, the six-plane form for the rays it cannot serve; slow, for tests */
+#define ACR_TRAVERSAL_NESTED    3  /* as AUTO, but frames with bounces on LDS-resident scenes also go through the kernel in which every
+                                     lane makes its object tests inside its own walk of the tree (AUTO hands them out across the wavefront) */
 
 typedef struct acr_hip_ctx acr_hip_ctx;
 
@@ -185,6 +187,7 @@ typedef struct acr_stats {
 	uint32_t six_plane_pixels;     /* pixels of that launch which were handed to the reference-order list pass (needs collect_stats) */
 	uint32_t block_order;          /* order in which that launch started its blocks of 16 x 16 pixel slots: ACR_BLOCK_ORDER_* */
 	uint32_t near_first;           /* 1 when that launch walked the mesh trees near side first (interval form, trees resident in HBM) */
+	uint32_t wave_tasks;           /* 1 when that launch handed its object tests out across each wavefront (frames with bounces, scene resident in LDS) */
 } acr_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

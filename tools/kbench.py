@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--extent", type=float, default=10.0)
     ap.add_argument("--aov", action="store_true", help="also write primitive ids and hit distances")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--nested", action="store_true", help="ACR_TRAVERSAL_NESTED: every lane makes its own object tests, also in frames with bounces")
     ap.add_argument("--nolights", action="store_true", help="drop the scene's lights (primary rays only)")
     ap.add_argument("--accumulate", choices=["identity", "sorted"], default=None,
                     help="time frames > 0 (running mean) through the identity pixel table or through the table sorted by traversal-path key")
@@ -66,6 +67,8 @@ def main():
     core.upload_scene(scene.soa)
     t_upload = time.perf_counter() - t0
     core.set_camera(scene.camera)
+    if args.nested:
+        core.set_traversal(nested=True)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
@@ -134,8 +137,18 @@ def main():
     out = dict(tag=args.tag or (args.lib or "default"), scene=("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
                size=args.size, bounces=args.bounces, ms_mean=float(ms.mean()), ms_min=float(ms.min()), ms_median=float(np.median(ms)),
                rays=int(rays), grays_per_s=rays / (float(np.median(ms)) * 1e-3) / 1e9, digest=digest,
-               six_plane_pixels=st.six_plane_pixels, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
+               six_plane_pixels=st.six_plane_pixels, wave_tasks=st.wave_tasks, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
     print(json.dumps(out), flush=True)
+    dbg = getattr(_capi.hip_lib(), "acr_dev_wave_debug", None)
+    if dbg is not None:  # experiment builds (-DACR_WAVE_DEBUG): totals over all launches of this run
+        v = (C.c_ulonglong * 16)()
+        dbg(v, 1)
+        print("wave debug: traces %d rays %d tasks %d overflow %d rounds %d | rays/trace %.1f tasks/ray %.2f rounds/trace %.2f"
+              % (v[0], v[1], v[2], v[3], v[4], v[1] / max(v[0], 1), v[2] / max(v[1], 1), v[4] / max(v[0], 1)), file=sys.stderr)
+        tot = max(v[9], 1)
+        print("wave clocks: A %.3f B %.3f C %.3f winner %.3f rest %.3f of the waves' time; per trace A %.0f B %.0f C %.0f winner %.0f ticks"
+              % (v[5] / tot, v[6] / tot, v[7] / tot, v[8] / tot, 1 - (v[5] + v[6] + v[7] + v[8]) / tot,
+                 v[5] / max(v[0], 1), v[6] / max(v[0], 1), v[7] / max(v[0], 1), v[8] / max(v[0], 1)), file=sys.stderr)
     core.close()
 
 
