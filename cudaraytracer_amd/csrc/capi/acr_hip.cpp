@@ -239,38 +239,54 @@ namespace
 	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false)
 	{
 		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
-		// six-plane traversal's undo column (the list pass runs in the same LDS block).  A deep mesh tree keeps
-		// only its deepest levels' waiting-child entries in LDS, so that the columns stay within what lets four
-		// workgroups share a CU (the kernel's register budget allows four); the levels above go to global memory.
-		constexpr size_t kColumnBudget = size_t(30) * 1024 * kBlock / 256;
-		uint32_t meshLdsLevels = h.max_mesh_depth;
+		// six-plane traversal's undo column (the list pass runs in the same LDS block).
 		const size_t perLevel = size_t(2) * kBlock * 4;
-		if (splitDeepColumns && (h.scene_depth + meshLdsLevels) * perLevel > kColumnBudget) {
-			const size_t fit = kColumnBudget / perLevel;
-			meshLdsLevels = fit > h.scene_depth + 4 ? uint32_t(fit - h.scene_depth) : 4u;
-			if (meshLdsLevels > h.max_mesh_depth) meshLdsLevels = h.max_mesh_depth;
-		}
-		const size_t intervalFloats = size_t(2) * (h.scene_depth + meshLdsLevels);
 		const size_t sixPlaneFloats = size_t(h.scene_depth) + h.max_mesh_depth;
-		// render launches run one form at a time in a workgroup and share the region; traceKernel runs both side by side
-		const size_t columnFloats = (splitDeepColumns ? (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) : intervalFloats + sixPlaneFloats) * kBlock;
-		const size_t stackBytes = (columnFloats + size_t(3) * colorLevels * kBlock) * 4;
+		auto layout = [&](uint32_t meshLdsLevels, size_t &columnFloats) {
+			const size_t intervalFloats = size_t(2) * (h.scene_depth + meshLdsLevels);
+			// render launches run one form at a time in a workgroup and share the region; traceKernel runs both side by side
+			columnFloats = (splitDeepColumns ? (intervalFloats > sixPlaneFloats ? intervalFloats : sixPlaneFloats) : intervalFloats + sixPlaneFloats) * kBlock;
+			return (columnFloats + size_t(3) * colorLevels * kBlock) * 4;
+		};
 		LaunchPlan p;
 		p.waveOff = 0;
+		p.meshGlobLevels = 0;
+		size_t columnFloats = 0;
+		size_t stackBytes = layout(h.max_mesh_depth, columnFloats);
+		p.cstackOff = uint32_t(columnFloats);
+		// the whole scene in LDS: kernels compiled for four waves per SIMD, i.e. four workgroups per CU
 		const size_t waveBytes = size_t(kBlock / 64) * acr::dev::waveLdsWords(h.num_objects) * 4;
 		if (waveTasks && h.num_objects <= acr::dev::kWaveMaxObjects && size_t(h.total_slots) * 16 + stackBytes + waveBytes <= kLdsBudget) {
 			p.ldsMode = 2;
 			p.stackSlot = h.total_slots;
 			p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes + waveBytes;
-			p.cstackOff = uint32_t(columnFloats);
 			p.waveOff = uint32_t(stackBytes / 4);
-			p.meshGlobLevels = 0;
 			return p;
 		}
 		if (size_t(h.total_slots) * 16 + stackBytes <= kLdsBudget) {
 			p.ldsMode = 2;
 			p.stackSlot = h.total_slots;
-		} else if (size_t(h.small_slots) * 16 + stackBytes <= kLdsBudget) {
+			p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
+			return p;
+		}
+		// Trees and triangles in HBM: those kernels are compiled for three waves per SIMD (no register spills), so
+		// three workgroups share a CU's 160 KiB.  A deep mesh tree keeps as many of its deepest levels' waiting-child
+		// entries in LDS as that allows (every level of a 22-level tree); the levels above go to global memory.
+		constexpr size_t kHbmBudget = size_t(52) * 1024;
+		uint32_t meshLdsLevels = h.max_mesh_depth;
+		if (splitDeepColumns) {
+			const size_t fixed = size_t(3) * colorLevels * kBlock * 4 + size_t(h.small_slots) * 16;
+			const size_t room = kHbmBudget > fixed ? kHbmBudget - fixed : 0;
+			const size_t fit = room / perLevel;
+			if (fit < size_t(h.scene_depth) + meshLdsLevels) {
+				meshLdsLevels = fit > size_t(h.scene_depth) + 4 ? uint32_t(fit - h.scene_depth) : 4u;
+				if (meshLdsLevels > h.max_mesh_depth) meshLdsLevels = h.max_mesh_depth;
+			}
+		}
+		stackBytes = layout(meshLdsLevels, columnFloats);
+		p.cstackOff = uint32_t(columnFloats);
+		p.meshGlobLevels = h.max_mesh_depth - meshLdsLevels;
+		if (size_t(h.small_slots) * 16 + stackBytes <= (splitDeepColumns ? kHbmBudget : kLdsBudget)) {
 			p.ldsMode = 1;
 			p.stackSlot = h.small_slots;
 		} else {
@@ -278,8 +294,6 @@ namespace
 			p.stackSlot = 0;
 		}
 		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
-		p.cstackOff = uint32_t(columnFloats);
-		p.meshGlobLevels = h.max_mesh_depth - meshLdsLevels;
 		return p;
 	}
 	// Makes list.dev hold `ids`.  A list equal to the previous one costs a memcmp; a new one waits for the

@@ -67,9 +67,11 @@ static_assert(ACR_BLOCK_SLOTS % ACR_BLOCK == 0 && ACR_BLOCK % 64 == 0, "a block 
 #ifndef ACR_RENDER_WAVES
 #define ACR_RENDER_WAVES 4
 #endif
-// the same for scenes whose trees and triangles are read from HBM (memory latency, not VALU issue, bounds those)
+// the same for scenes whose trees and triangles are read from HBM: three, four and five waves run equally fast there
+// (the length of the slowest waves bounds those frames), and three leave the kernel enough registers to spill nothing
+// and a workgroup enough LDS for every level of a deep tree's waiting-child column
 #ifndef ACR_RENDER_WAVES_HBM
-#define ACR_RENDER_WAVES_HBM 5
+#define ACR_RENDER_WAVES_HBM 3
 #endif
 
 // waves per SIMD the wave-cooperative kernel is compiled for
@@ -1229,16 +1231,21 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 #define ACR_DBG_PHASE(n)
 #endif
 	waveSync(); // the previous call's step C has read the tables
-	// step A.  The object records are the same for every lane: read through the global pointer with a uniform
-	// index they come in over the scalar cache, not out of LDS.  Lane k keeps object k's ballot and list offset
-	// and all of them are stored at once after the loop.
+	// step A.  Object k + 1's box is requested before object k's is tested; lane k keeps object k's ballot and list
+	// offset and all of them are stored at once after the loop.
 	const float tLimit = SHADOW ? lightT : FLT_MAX; // info.t as the traversal starts; it only shrinks afterwards
 	uint32_t total = 0;
 	uint32_t keepLo = 0, keepHi = 0, keepOff = 0;
 	uint64_t candMask = 0;
+	uint4 nb0 = mem.small(sc.off_objects), nb1 = mem.small(sc.off_objects + 1); // slots the staging copy has filled even for an empty scene's header
 	for (uint32_t k = 0; k < sc.num_objects; k++) {
-		const uint32_t os = sc.off_objects + k * kObjectSlots;
-		const uint4 b0 = mem.g[os], b1 = mem.g[os + 1];
+		const uint4 b0 = nb0, b1 = nb1;
+		{
+			// the record after the last object's is whatever follows in the blob: read, never used
+			const uint32_t osn = sc.off_objects + (k + 1 < sc.num_objects ? k + 1 : k) * kObjectSlots;
+			nb0 = mem.small(osn);
+			nb1 = mem.small(osn + 1);
+		}
 		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
 		const Interval wb = boxInterval(sa, wmin, wmax);
 		const bool cand = part && (!(b0.w & kObjPrefilter) || intervalHit(wb.tmin, wb.tmax, tLimit));
@@ -1417,7 +1424,8 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		oldx = (vblock % p.blocks_x) * 16u + lx;
 		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
 	}
-	Counters &cnt = res.cnt;
+	// ray counts of this lane in one register: shadow rays in bits 0-19, bounce rays in 20-27, the primary hit in 28
+	uint32_t counts = 0;
 	res.active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
 	bool alive = res.active;
 
@@ -1446,9 +1454,27 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 	r.d = getPixelDir(p, i, -j);
 
 	vec3 source(1, 1, 1);
-	vec4 tail(0, 0, 0, 1);
 	uint32_t kept = 0; // direct terms of this lane waiting in cstack
 	bool bail = false;
+	// A path's pixel is written on the level it ends on: Color4(c_0,1) + (Color4(c_1,1) + (... + tail)), the
+	// recursion's association, then the running mean of renderer.cu:375-387.
+	auto writePixel = [&](vec4 contribution) {
+		while (kept > 0) {
+			kept--;
+			const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
+			contribution = cl + contribution;
+		}
+		float4 *px = p.screen + outSlot;
+		if (p.frames > 0) {
+			const float4 old = *px;
+			vec4 s(old.x, old.y, old.z, old.w);
+			s = s * (float(p.frames) / float(p.frames + 1));
+			s = s + (contribution / float(p.frames + 1));
+			*px = make_float4(s.x, s.y, s.z, s.w);
+		} else {
+			*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
+		}
+	};
 	if (alive) {
 		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
 		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
@@ -1462,13 +1488,18 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		info.prim = 0xFFFFFFFFu;
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
-		if (alive && level > 0) cnt.bounce++;
+		if (alive && level > 0) counts += 1u << 20;
 		const bool hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
-		if (alive && (bail || !hit)) alive = false; // a miss: renderer.cu:315
+		bool ended = false;
+		vec4 tail(0, 0, 0, 1);
+		if (alive && (bail || !hit)) { // a miss: renderer.cu:315
+			alive = false;
+			ended = !bail;
+		}
 		if (alive && level == 0) {
 			if (p.primid) p.primid[outSlot] = info.prim;
 			if (p.hit_t) p.hit_t[outSlot] = info.t;
-			cnt.primaryHits++;
+			counts |= 1u << 28;
 		}
 		// direct illum (renderer.cu:247-248): Scene::lightPoint (scene.cu:273-292), the lights in step across the wave
 		vec3 lightSum(0, 0, 0);
@@ -1511,7 +1542,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 						}
 					}
 				}
-				if (trace) cnt.shadow++;
+				if (trace) counts++;
 			}
 			Ray sr;
 			sr.o = info.position;
@@ -1578,9 +1609,11 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			if (absorbed) {
 				tail = vec4(c, 1);
 				alive = false;
+				ended = true;
 			} else if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
 				tail = vec4(c, 1) + vec4(0, 0, 0, 1);
 				alive = false;
+				ended = true;
 			} else {
 				// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
 				cstack[(3 * level + 0) * kBlock] = c.x;
@@ -1591,32 +1624,15 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 				source = nSource;
 			}
 		}
+		if (ended) writePixel(tail);
 	}
-	if (!res.active)
-		return res;
+	if (alive) writePixel(vec4(0, 0, 0, 1)); // max_bounces == 0: rayColor<0> alone
 	if (bail) {
 		// nothing of this pixel is kept: the six-plane pass renders it from the start
 		res.bail = true;
-		res.cnt = {0, 0, 0};
 		return res;
 	}
-	vec4 contribution = tail;
-	while (kept > 0) {
-		kept--;
-		const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
-		contribution = cl + contribution;
-	}
-	// average (renderer.cu:375-387)
-	float4 *px = p.screen + outSlot;
-	if (p.frames > 0) {
-		const float4 old = *px;
-		vec4 s(old.x, old.y, old.z, old.w);
-		s = s * (float(p.frames) / float(p.frames + 1));
-		s = s + (contribution / float(p.frames + 1));
-		*px = make_float4(s.x, s.y, s.z, s.w);
-	} else {
-		*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
-	}
+	res.cnt = {counts & 0xFFFFFu, (counts >> 20) & 0xFFu, counts >> 28};
 	return res;
 }
 
