@@ -777,7 +777,8 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 
 	// Frames with bounces on scenes that fit LDS are rendered by the wave-cooperative kernel (object tests as tasks
 	// compacted across the wavefront), if its tables fit as well.
-	const bool wantWave = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && f->max_bounces > 1 && !f->path_keys_dev;
+	const bool wantWave = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && f->max_bounces > 1 && !f->path_keys_dev &&
+	                      uint64_t(grid) * kBlock < (1ull << 32); // that kernel numbers its pixel slots in 32 bits
 	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;

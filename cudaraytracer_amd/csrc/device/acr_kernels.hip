@@ -1175,8 +1175,8 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 //      tests against the current info.t, same order -- and where the reference calls Object::intersect it
 //      looks the result up: info is replaced iff t < info.t (scene.cu:432), `intersected` accumulates.
 // For a closest-hit query the winning object is tested once more for position, normal and primitive id.
-// A task list holds kWaveTaskSlots entries per lane on average; a candidate that does not fit is tested by its
-// own lane during step C, as the nested kernel does.
+// A task list holds kWaveCap entries; when the rays of a wave have more candidates than that, steps B and C are
+// made for one group of consecutive lanes after the other (all lanes work on every group's tasks).
 
 #ifdef ACR_WAVE_DEBUG
 // experiment builds only: wave traces, rays, tasks, tasks beyond the list, rounds of step B
@@ -1210,8 +1210,10 @@ __device__ __forceinline__ void waveSync()
 // otherwise returns `intersected` and fills info (position, normal, material, prim of the closest hit).
 template <bool SHADOW, class Mem>
 __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHeader &sc, const WaveLds &wl, bool active, const Ray &r, WorldHit &info,
-                                                   float lightT, const Columns &col, bool &bail)
+                                                   float lightT, const Columns &col, bool &bailOut)
 {
+	bool bail = false;
+	bool testBail = false; // the one flag every object test below reports through
 	const uint32_t lane = threadIdx.x & 63u;
 	SlabArgs sa;
 	sa.o = vec3(0, 0, 0);
@@ -1230,122 +1232,142 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 #else
 #define ACR_DBG_PHASE(n)
 #endif
-	waveSync(); // the previous call's step C has read the tables
-	// step A.  Object k + 1's box is requested before object k's is tested; lane k keeps object k's ballot and list
-	// offset and all of them are stored at once after the loop.
+	// step A: which objects' grown boxes does this lane's ray enter?  Object k + 1's box is requested before
+	// object k's is tested.
 	const float tLimit = SHADOW ? lightT : FLT_MAX; // info.t as the traversal starts; it only shrinks afterwards
-	uint32_t total = 0;
-	uint32_t keepLo = 0, keepHi = 0, keepOff = 0;
 	uint64_t candMask = 0;
-	uint4 nb0 = mem.small(sc.off_objects), nb1 = mem.small(sc.off_objects + 1); // slots the staging copy has filled even for an empty scene's header
-	for (uint32_t k = 0; k < sc.num_objects; k++) {
-		const uint4 b0 = nb0, b1 = nb1;
-		{
-			// the record after the last object's is whatever follows in the blob: read, never used
-			const uint32_t osn = sc.off_objects + (k + 1 < sc.num_objects ? k + 1 : k) * kObjectSlots;
-			nb0 = mem.small(osn);
-			nb1 = mem.small(osn + 1);
-		}
-		const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
-		const Interval wb = boxInterval(sa, wmin, wmax);
-		const bool cand = part && (!(b0.w & kObjPrefilter) || intervalHit(wb.tmin, wb.tmax, tLimit));
-		const uint64_t bal = __ballot(cand);
-		const bool mine = lane == k;
-		keepLo = mine ? uint32_t(bal) : keepLo;
-		keepHi = mine ? uint32_t(bal >> 32) : keepHi;
-		keepOff = mine ? total : keepOff;
-		if (cand) {
-			candMask |= 1ull << k;
-			const uint32_t slot = total + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u));
-			if (slot < kWaveCap) wl.queue[slot] = uint16_t(lane | (k << 6));
-		}
-		total += uint32_t(__popcll(bal));
-	}
-	if (lane < sc.num_objects) {
-		wl.ballotLo[lane] = keepLo;
-		wl.ballotHi[lane] = keepHi;
-		wl.offset[lane] = keepOff;
-	}
-	const uint32_t queued = total < kWaveCap ? total : kWaveCap;
-#ifdef ACR_WAVE_DEBUG
 	{
-		const uint64_t pb = __ballot(part);
-		g_dbgAcc[0] += 1;
-		g_dbgAcc[1] += __popcll(pb);
-		g_dbgAcc[2] += total;
-		g_dbgAcc[3] += total - queued;
-		g_dbgAcc[4] += (queued + 63) / 64;
-	}
-#endif
-	waveSync();
-	ACR_DBG_PHASE(5)
-	// step B: the ray of task (lane rl, object obj) comes straight out of lane rl's registers
-	for (uint32_t base = 0; base < queued; base += 64u) {
-		const uint32_t task = base + lane;
-		const bool valid = task < queued;
-		const uint32_t e = valid ? uint32_t(wl.queue[task]) : 0u;
-		const int rl = int(e & 63u);
-		Ray tr;
-		tr.o = vec3(__shfl(r.o.x, rl, 64), __shfl(r.o.y, rl, 64), __shfl(r.o.z, rl, 64));
-		tr.d = vec3(__shfl(r.d.x, rl, 64), __shfl(r.d.y, rl, 64), __shfl(r.d.z, rl, 64));
-		if (valid) {
-			WorldHit th;
-			th.t = FLT_MAX;
-			bool tb = false;
-			const bool hit = objectIntersect<false, true, false>(mem, sc, e >> 6, tr, sa, th, col, tb, FLT_MAX);
-			wl.results[task] = th.t;
-			wl.queue[task] = uint16_t(e | (hit ? kTaskHit : 0u) | (tb ? kTaskBail : 0u));
+		uint4 nb0 = mem.small(sc.off_objects), nb1 = mem.small(sc.off_objects + 1); // slots the staging copy has filled even for an empty scene
+		for (uint32_t k = 0; k < sc.num_objects; k++) {
+			const uint4 b0 = nb0, b1 = nb1;
+			{
+				// after the last object the same record once more: read, never used
+				const uint32_t osn = sc.off_objects + (k + 1 < sc.num_objects ? k + 1 : k) * kObjectSlots;
+				nb0 = mem.small(osn);
+				nb1 = mem.small(osn + 1);
+			}
+			const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
+			const Interval wb = boxInterval(sa, wmin, wmax);
+			const bool cand = part && (!(b0.w & kObjPrefilter) || intervalHit(wb.tmin, wb.tmax, tLimit));
+			candMask |= cand ? 1ull << k : 0ull;
 		}
 	}
-	waveSync();
-	ACR_DBG_PHASE(6)
-	// step C
-	bool intersected = false, occluded = false;
+	// Tasks of the lanes before and including this one.  A task list holds kWaveCap entries: the lanes are served in
+	// groups of consecutive lanes whose tasks fit (one group, nearly always; a lane alone always fits, as there
+	// are at most 64 objects).
+	uint32_t incl = uint32_t(__popcll(candMask));
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t v = __shfl_up(incl, d, 64);
+		incl += lane >= uint32_t(d) ? v : 0u;
+	}
+	ACR_DBG_PHASE(5)
+	// how a walk of step C ended early: one variable for both reasons (two flags set to `true` on two ways out of
+	// the same loop end up as one store through a selected address, which pins both flags in scratch memory)
+	constexpr uint32_t kEndOccluded = 1u, kEndBail = 2u;
+	bool intersected = false;
+	uint32_t ended = 0;
 	uint32_t best = 0;
-	if (part) {
-		const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
-		auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
-		auto leaf = [&](uint32_t start, uint32_t end) {
-			for (uint32_t i = start; i < end; i++) {
-				if (!((candMask >> i) & 1ull))
-					continue; // the ray misses the object's grown box: Object::intersect returns false, info untouched
-				const uint32_t lo = wl.ballotLo[i], hi = wl.ballotHi[i];
-				const uint32_t slot = wl.offset[i] + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-				bool hit;
-				float t;
-				if (slot < kWaveCap) {
+	uint32_t groupLo = 0, groupBase = 0;
+	for (;;) {
+		const bool inGroup = lane >= groupLo && incl - groupBase <= kWaveCap;
+		const uint32_t groupHi = groupLo + uint32_t(__popcll(__ballot(inGroup)));
+		waveSync(); // the previous group's (or call's) step C has read the tables
+		// the group's task list: lane k keeps object k's ballot and list offset, stored at once after the loop
+		uint32_t queued = 0;
+		uint32_t keepLo = 0, keepHi = 0, keepOff = 0;
+		for (uint32_t k = 0; k < sc.num_objects; k++) {
+			const bool cand = inGroup && ((candMask >> k) & 1ull) != 0;
+			const uint64_t bal = __ballot(cand);
+			const bool mine = lane == k;
+			keepLo = mine ? uint32_t(bal) : keepLo;
+			keepHi = mine ? uint32_t(bal >> 32) : keepHi;
+			keepOff = mine ? queued : keepOff;
+			if (cand)
+				wl.queue[queued + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u))] = uint16_t(lane | (k << 6));
+			queued += uint32_t(__popcll(bal));
+		}
+		if (lane < sc.num_objects) {
+			wl.ballotLo[lane] = keepLo;
+			wl.ballotHi[lane] = keepHi;
+			wl.offset[lane] = keepOff;
+		}
+#ifdef ACR_WAVE_DEBUG
+		{
+			const uint64_t pb = __ballot(part && inGroup);
+			g_dbgAcc[0] += groupLo == 0 ? 1 : 0;
+			g_dbgAcc[1] += __popcll(pb);
+			g_dbgAcc[2] += queued;
+			g_dbgAcc[3] += groupLo == 0 ? 0 : 1;
+			g_dbgAcc[4] += (queued + 63) / 64;
+		}
+#endif
+		waveSync();
+		ACR_DBG_PHASE(5)
+		// step B: the ray of task (lane rl, object obj) comes straight out of lane rl's registers
+		for (uint32_t base = 0; base < queued; base += 64u) {
+			const uint32_t task = base + lane;
+			const bool valid = task < queued;
+			const uint32_t e = valid ? uint32_t(wl.queue[task]) : 0u;
+			const int rl = int(e & 63u);
+			Ray tr;
+			tr.o = vec3(__shfl(r.o.x, rl, 64), __shfl(r.o.y, rl, 64), __shfl(r.o.z, rl, 64));
+			tr.d = vec3(__shfl(r.d.x, rl, 64), __shfl(r.d.y, rl, 64), __shfl(r.d.z, rl, 64));
+			if (valid) {
+				WorldHit th;
+				th.t = FLT_MAX;
+				testBail = false;
+				const bool hit = objectIntersect<false, true, false>(mem, sc, e >> 6, tr, sa, th, col, testBail, FLT_MAX);
+				wl.results[task] = th.t;
+				wl.queue[task] = uint16_t(e | (hit ? kTaskHit : 0u) | (testBail ? kTaskBail : 0u));
+			}
+		}
+		waveSync();
+		ACR_DBG_PHASE(6)
+		// step C
+		if (part && inGroup) {
+			const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
+			auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
+			auto leaf = [&](uint32_t start, uint32_t end) {
+				for (uint32_t i = start; i < end; i++) {
+					if (!((candMask >> i) & 1ull))
+						continue; // the ray misses the object's grown box: Object::intersect returns false, info untouched
+					const uint32_t slot = wl.offset[i] + __builtin_amdgcn_mbcnt_hi(wl.ballotHi[i], __builtin_amdgcn_mbcnt_lo(wl.ballotLo[i], 0u));
 					const uint32_t e = wl.queue[slot];
-					hit = (e & kTaskHit) != 0;
-					if (e & kTaskBail) bail = true;
-					t = wl.results[slot];
-				} else {
-					WorldHit th;
-					th.t = FLT_MAX;
-					hit = objectIntersect<false, true, false>(mem, sc, i, r, sa, th, col, bail, FLT_MAX);
-					t = th.t;
-				}
-				if (bail) return true;
-				intersected |= hit;
-				if (hit && t < info.t) { // scene.cu:432
-					info.t = t;
-					best = i;
-				}
-				if constexpr (SHADOW) {
-					if (info.t + epsilon() < lightT) {
-						occluded = true;
+					const bool hit = (e & kTaskHit) != 0;
+					const float t = wl.results[slot];
+					if (e & kTaskBail) {
+						ended = kEndBail;
 						return true;
 					}
+					intersected |= hit;
+					if (hit && t < info.t) { // scene.cu:432
+						info.t = t;
+						best = i;
+					}
+					if constexpr (SHADOW) {
+						if (info.t + epsilon() < lightT) {
+							ended = kEndOccluded;
+							return true;
+						}
+					}
 				}
-			}
-			return false;
-		};
-		auto tcur = [&]() { return info.t; };
-		const LevelColumn lc = {reinterpret_cast<float2 *>(col.scene), nullptr, 0u, 0u};
-		bihTraverseFast(loadNode, sa, boxInterval(sa, smin, smax), lc, leaf, tcur);
+				return false;
+			};
+			auto tcur = [&]() { return info.t; };
+			const LevelColumn lc = {reinterpret_cast<float2 *>(col.scene), nullptr, 0u, 0u};
+			bihTraverseFast(loadNode, sa, boxInterval(sa, smin, smax), lc, leaf, tcur);
+		}
+		if (groupHi >= 64u)
+			break;
+		groupBase = uint32_t(__shfl(incl, int(groupHi) - 1, 64));
+		groupLo = groupHi;
 	}
 	ACR_DBG_PHASE(7)
+	bail = bail || ended == kEndBail;
 	if constexpr (SHADOW) {
-		return occluded;
+		bailOut = bailOut || bail;
+		return ended == kEndOccluded;
 	} else {
 		// the closest hit once more, this time for everything a shaded hit needs
 		if (part && !bail && intersected && info.t < FLT_MAX) {
@@ -1355,10 +1377,13 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 			full.prim = 0xFFFFFFFFu;
 			full.position = vec3(0, 0, 0);
 			full.normal = vec3(0, 0, 0);
-			objectIntersect<true, true, false>(mem, sc, best, r, sa, full, col, bail, FLT_MAX);
+			testBail = false;
+			objectIntersect<true, true, false>(mem, sc, best, r, sa, full, col, testBail, FLT_MAX);
+			bail = bail || testBail;
 			info = full;
 		}
 		ACR_DBG_PHASE(8)
+		bailOut = bailOut || bail;
 		return intersected;
 	}
 }
@@ -1409,7 +1434,15 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 	res.bail = false;
 	res.cnt = {0, 0, 0};
 	uint32_t oldx, oldy;
-	size_t outSlot = 0;
+	// Where this lane's pixel lies in the output buffers.  Kept as one 32-bit number, and the 64-bit addresses are
+	// formed where they are used (behind an empty asm statement, or the compiler computes them up front and keeps
+	// six registers busy through every traversal).
+	uint32_t outSlot = 0;
+	auto slotNow = [&]() {
+		uint32_t v = outSlot;
+		asm volatile("" : "+v"(v));
+		return size_t(v);
+	};
 	const bool tiled = p.num_tiles != 0;
 	if (tiled) {
 		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
@@ -1419,7 +1452,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
 		oldx = (tile % p.tiles_x) * p.tile_w + inx;
 		oldy = (tile / p.tiles_x) * p.tile_h + iny;
-		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
+		outSlot = tileNo * p.tile_w * p.tile_h + iny * p.tile_w + inx; // below 2^32: the launch's slot count is
 	} else {
 		oldx = (vblock % p.blocks_x) * 16u + lx;
 		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
@@ -1443,7 +1476,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			x = index % width;
 			y = index / width;
 		}
-		if (!tiled) outSlot = size_t(index);
+		if (!tiled) outSlot = uint32_t(index);
 	}
 	RandState state;
 	randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
@@ -1464,7 +1497,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
 			contribution = cl + contribution;
 		}
-		float4 *px = p.screen + outSlot;
+		float4 *px = p.screen + slotNow();
 		if (p.frames > 0) {
 			const float4 old = *px;
 			vec4 s(old.x, old.y, old.z, old.w);
@@ -1476,8 +1509,8 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		}
 	};
 	if (alive) {
-		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
-		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
+		if (p.primid) p.primid[slotNow()] = 0xFFFFFFFFu;
+		if (p.hit_t) p.hit_t[slotNow()] = FLT_MAX;
 	}
 	for (uint32_t level = 0; level < maxBounces; level++) { // rayColor<0> (renderer.cu:318-324) is the initial `tail`
 		if (!__any(alive))
@@ -1497,8 +1530,8 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			ended = !bail;
 		}
 		if (alive && level == 0) {
-			if (p.primid) p.primid[outSlot] = info.prim;
-			if (p.hit_t) p.hit_t[outSlot] = info.t;
+			if (p.primid) p.primid[slotNow()] = info.prim;
+			if (p.hit_t) p.hit_t[slotNow()] = info.t;
 			counts |= 1u << 28;
 		}
 		// direct illum (renderer.cu:247-248): Scene::lightPoint (scene.cu:273-292), the lights in step across the wave
