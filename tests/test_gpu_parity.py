@@ -776,3 +776,61 @@ def test_list_pass_on_a_small_frame_of_a_deep_tree(core, acr, orc):
     assert st2.six_plane_pixels >= w * h
     assert_same(img2, pid2, ht2, st2, ref)
     assert (pid2 != 0xFFFFFFFF).mean() > 0.05
+
+
+def test_cornell_4k_four_bounces_full_size(core, built):
+    """The 4K, four-bounce configuration at its full size: 3840 x 2160, max_bounces 4, every pixel against the
+    oracle; then the properties that do not depend on size: the wave-cooperative kernel (object tests handed out
+    across each wavefront), the kernel in which every lane makes its own, and the six-plane form give one and
+    the same frame, and a tile list reproduces the same pixels."""
+    import torch
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h, bounces, seed = 3840, 2160, 4, 12345
+    ref = b.oracle.render(w, h, seed=seed, frames=0, max_bounces=bounces)
+    img, pid, ht, st = render(core, w, h, seed=seed, frames=0, max_bounces=bounces)
+    assert st.scene_in_lds == 2 and st.interval_traversal == 1 and st.wave_tasks == 1
+    assert_same(img, pid, ht, st, ref)
+    del ref
+    miss = pid == 0xFFFFFFFF
+    assert np.all(ht[miss] == FMAX) and np.all(img[miss][:, :3] == 0) and np.all(img[miss][:, 3] == 1)
+    assert np.isfinite(img).all() and pid[~miss].max() < 72 and 0.54 < (~miss).mean() < 0.56
+    assert img[..., 3].max() <= bounces + 1 and st.rays_bounce > st.primary_hits  # most paths go on after the first hit
+    for mode in (dict(nested=True), dict(six_plane_only=True)):
+        core.set_traversal(**mode)
+        try:
+            img2, pid2, ht2, st2 = render(core, w, h, seed=seed, frames=0, max_bounces=bounces)
+        finally:
+            core.set_traversal()
+        assert st2.wave_tasks == 0 and st2.interval_traversal == (0 if "six_plane_only" in mode else 1)
+        assert np.array_equal(pid2, pid) and np.array_equal(ht2.view(np.uint32), ht.view(np.uint32))
+        assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+        assert (st2.rays_shadow, st2.rays_bounce, st2.primary_hits) == (st.rays_shadow, st.rays_bounce, st.primary_hits)
+    tw, th = 3840, 16  # full-width bands, the multi-GPU layout
+    ids = np.array([134, 0, 77, 40], dtype=np.uint32)
+    tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        core.render(w, h, seed=seed, frames=0, max_bounces=bounces, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
+        core.sync()
+    finally:
+        core.use_own_stream()
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for n, tid in enumerate(ids):
+        y0 = int(tid) * th
+        assert np.array_equal(t[n].view(np.uint32), img[y0:y0 + th].view(np.uint32))
+
+
+def test_flythrough_camera_full_size(core, built):
+    """one camera of the 120-frame flythrough at the size the flythrough is benchmarked at, every pixel"""
+    from cudaraytracer_amd import camera_path
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    cams = camera_path.flythrough(b.scene.camera, 120)
+    try:
+        core.set_camera(cams[90])
+        img, pid, ht, st = render(core, 1920, 1080, seed=777, frames=0, max_bounces=1)
+        assert_same(img, pid, ht, st, b.oracle.render(1920, 1080, seed=777, frames=0, max_bounces=1, camera=orc_camera(cams[90])))
+        assert 0.3 < (pid != 0xFFFFFFFF).mean() < 0.9
+    finally:
+        core.set_camera(b.scene.camera)
