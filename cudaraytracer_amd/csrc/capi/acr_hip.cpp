@@ -65,12 +65,24 @@ struct acr_hip_ctx
 
 	// per-launch scratch
 	unsigned long long *counters = nullptr; // device [kCounterSlots][4]
-	// device copies of the last tile lists (render / scatter); re-uploaded only when the list changes
+	// Device copies of the tile lists (render / scatter).  A list equal to the previous one is not uploaded again.
+	// A new one goes into the next of kTileRing slots: pinned host memory, a device buffer and an event recorded
+	// behind the launch that reads the slot, so that a caller which changes its list with every frame (per-frame
+	// rebalancing across GPUs) never waits for the stream: the slot it overwrites was last read kTileRing
+	// launches ago.
+	static constexpr int kTileRing = 4;
 	struct TileList
 	{
-		uint32_t *dev = nullptr;
-		size_t cap = 0;
-		std::vector<uint32_t> host;
+		struct Slot
+		{
+			uint32_t *dev = nullptr, *pinned = nullptr;
+			size_t cap = 0;
+			hipEvent_t read = nullptr; // recorded after the last launch that reads dev
+			bool inUse = false;
+		} slot[kTileRing];
+		int current = -1;
+		std::vector<uint32_t> host; // contents of slot[current]
+		uint32_t *dev() const { return current < 0 ? nullptr : slot[current].dev; }
 	} renderTiles, scatterTiles;
 	// interval traversal (see acr_kernels.hip): usable for this scene, forced off by the caller, and the
 	// buffers through which its launches hand pixels to the six-plane list pass
@@ -296,22 +308,38 @@ namespace
 		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
 		return p;
 	}
-	// Makes list.dev hold `ids`.  A list equal to the previous one costs a memcmp; a new one waits for the
-	// stream (earlier launches may still read the old copy) and uploads.
+	// Makes list.dev() hold `ids`.  A list equal to the previous one costs a memcmp; a new one is queued into the
+	// next ring slot with an asynchronous copy from pinned memory (see TileList).  The caller records the slot's
+	// event after the launch that reads it (tileListRead).
 	int syncTileList(acr_hip_ctx *ctx, acr_hip_ctx::TileList &list, const uint32_t *ids, uint32_t n)
 	{
-		if (list.host.size() == n && memcmp(list.host.data(), ids, sizeof(uint32_t) * n) == 0) return ACR_OK;
-		ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (list.cap < n) {
-			(void)hipFree(list.dev);
-			list.dev = nullptr;
-			list.cap = 0;
-			list.host.clear();
-			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&list.dev), sizeof(uint32_t) * n));
-			list.cap = n;
+		if (list.current >= 0 && list.host.size() == n && memcmp(list.host.data(), ids, sizeof(uint32_t) * n) == 0) return ACR_OK;
+		const int next = (list.current + 1) % acr_hip_ctx::kTileRing;
+		acr_hip_ctx::TileList::Slot &s = list.slot[next];
+		if (!s.read) ACR_HIP_TRY(ctx, hipEventCreateWithFlags(&s.read, hipEventDisableTiming));
+		if (s.inUse) ACR_HIP_TRY(ctx, hipEventSynchronize(s.read)); // a launch kTileRing lists ago: long over
+		if (s.cap < n) {
+			(void)hipFree(s.dev);
+			(void)hipHostFree(s.pinned);
+			s.dev = s.pinned = nullptr;
+			s.cap = 0;
+			const size_t cap = size_t(n) + n / 2 + 64; // lists of a rebalanced split vary in length: grow with room
+			ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s.dev), sizeof(uint32_t) * cap));
+			ACR_HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&s.pinned), sizeof(uint32_t) * cap, hipHostMallocDefault));
+			s.cap = cap;
 		}
+		memcpy(s.pinned, ids, sizeof(uint32_t) * n);
+		ACR_HIP_TRY(ctx, hipMemcpyAsync(s.dev, s.pinned, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
 		list.host.assign(ids, ids + n);
-		ACR_HIP_TRY(ctx, hipMemcpy(list.dev, list.host.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+		list.current = next;
+		s.inUse = true;
+		// until the first reader is queued the copy itself is what must finish before the slot is reused
+		ACR_HIP_TRY(ctx, hipEventRecord(s.read, ctx->stream));
+		return ACR_OK;
+	}
+	int tileListRead(acr_hip_ctx *ctx, acr_hip_ctx::TileList &list)
+	{
+		if (list.current >= 0) ACR_HIP_TRY(ctx, hipEventRecord(list.slot[list.current].read, ctx->stream));
 		return ACR_OK;
 	}
 } // namespace
@@ -368,8 +396,12 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->sortTemp);
 	(void)hipFree(ctx->sortKeysOut);
 	(void)hipFree(ctx->sortValuesIn);
-	(void)hipFree(ctx->renderTiles.dev);
-	(void)hipFree(ctx->scatterTiles.dev);
+	for (acr_hip_ctx::TileList *l : {&ctx->renderTiles, &ctx->scatterTiles})
+		for (auto &sl : l->slot) {
+			(void)hipFree(sl.dev);
+			(void)hipHostFree(sl.pinned);
+			if (sl.read) (void)hipEventDestroy(sl.read);
+		}
 	if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
 	if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
 	if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -381,6 +413,11 @@ const char *acr_hip_last_error(const acr_hip_ctx *ctx) { return ctx ? ctx->error
 int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return ACR_ERR_INVALID;
+	if (ctx->stream != static_cast<hipStream_t>(hip_stream)) {
+		// tile lists queued on the old stream are not ordered against the new one: have them uploaded again
+		ctx->renderTiles.host.clear();
+		ctx->scatterTiles.host.clear();
+	}
 	ctx->stream = static_cast<hipStream_t>(hip_stream);
 	return ACR_OK;
 }
@@ -388,6 +425,10 @@ int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream)
 int acr_hip_use_own_stream(acr_hip_ctx *ctx)
 {
 	if (!ctx) return ACR_ERR_INVALID;
+	if (ctx->stream != ctx->ownStream) {
+		ctx->renderTiles.host.clear();
+		ctx->scatterTiles.host.clear();
+	}
 	ctx->stream = ctx->ownStream;
 	return ACR_OK;
 }
@@ -722,7 +763,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	p.tile_h = f->tile_h;
 	p.tiles_x = tilesX;
 	p.num_tiles = f->num_tiles;
-	p.tile_ids = ctx->renderTiles.dev;
+	p.tile_ids = tiled ? ctx->renderTiles.dev() : nullptr;
 	p.pixel_values = f->pixel_values_dev;
 	p.path_keys = f->path_keys_dev;
 	// Launch order of the blocks: the caller's table, else the context's own (measured every blockOrderEvery-th
@@ -854,6 +895,10 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (fast ? 1 : 0)), grid, plan.ldsBytes, ctx->stream));
 	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
 	if (fast && !staticOnly) ctx->redoParity ^= 1u;
+	if (tiled) {
+		const int rc = tileListRead(ctx, ctx->renderTiles);
+		if (rc != ACR_OK) return rc;
+	}
 	ctx->statsStatic = staticOnly;
 	if (ctx->timed) ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStop, ctx->stream));
 	const uint32_t orderUsed = f->block_order_dev ? ACR_BLOCK_ORDER_CALLER : (p.block_order ? ACR_BLOCK_ORDER_MEASURED : ACR_BLOCK_ORDER_NATURAL);
@@ -1045,8 +1090,8 @@ int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const int rc = syncTileList(ctx, ctx->scatterTiles, tile_ids, num_tiles);
 	if (rc != ACR_OK) return rc;
-	ACR_HIP_TRY(ctx, acr_dev_launch_scatter_tiles(tiles_dev, ctx->scatterTiles.dev, num_tiles, tile_w, tile_h, width, height, frame_dev, ctx->stream));
-	return ACR_OK;
+	ACR_HIP_TRY(ctx, acr_dev_launch_scatter_tiles(tiles_dev, ctx->scatterTiles.dev(), num_tiles, tile_w, tile_h, width, height, frame_dev, ctx->stream));
+	return tileListRead(ctx, ctx->scatterTiles);
 }
 
 } // extern "C"

@@ -145,6 +145,15 @@ def solve_shares(measurements, num_tiles):
         else:
             lo = mid
     b = bands_within(hi)
+    # No rank is left without work: a rank the model would give less than one band (a rank far slower than the
+    # others, or a measurement taken while something else used the device or the link) still gets one, and the
+    # caller is told, since frames will then take as long as that rank's band.
+    if num_tiles >= world and (b < 1.0).any():
+        import warnings
+        warnings.warn("multi-GPU shares: the measured speeds give rank(s) %s less than one band of the frame; they are held at one band "
+                      "(render s %s, send s %s)" % ([int(r) for r in np.nonzero(b < 1.0)[0]], np.round(times[:, 0], 6).tolist(),
+                                                    np.round(times[:, 1], 6).tolist()), RuntimeWarning, stacklevel=2)
+        b = np.maximum(b, 1.0)
     return b / b.sum()
 
 
@@ -203,6 +212,13 @@ class DistributedRenderer:
         self._last_slot = 0
         self.calibration = None
         self._calibrations = []  # (bands per rank, [render s, send s] per rank) of each calibrate() call
+        # Costs measured on frame k decide the split from frame k + cost_lag on: their sum over the ranks and the copy
+        # to the host are queued behind frame k and only waited for when frame k + cost_lag starts, so that a split
+        # rebuilt every frame (camera flythrough) keeps `depth` frames in flight.  Every rank applies the update
+        # at the same frame number, hence the same split everywhere.
+        self.cost_lag = self.depth if self.bands else 1
+        self._cost_updates = []  # (frame number to apply at, host tensor, event / work)
+        self.last_split = None
 
     @property
     def frame(self):
@@ -212,8 +228,27 @@ class DistributedRenderer:
         return self.frames[(self.frame_no - 1) % len(self.frames)] if self.frame_no else self.frames[0]
 
     def camera_moved(self):
+        """No history applies to the new view: uniform costs again, and costs still on their way belong to the old view."""
         self.frames_since_rebalance = 0
+        self._drop_cost_updates()
         self.plan.reset()
+
+    def _drop_cost_updates(self):
+        for _, _, ready in self._cost_updates:
+            if ready is not None:
+                ready.synchronize() if hasattr(ready, "synchronize") else ready.wait()
+        self._cost_updates = []
+
+    def _apply_cost_updates(self):
+        """Rebuilds the split from every cost vector that is due at this frame number."""
+        p = self.plan
+        while self._cost_updates and self._cost_updates[0][0] <= self.frame_no:
+            _, host, ready = self._cost_updates.pop(0)
+            if ready is not None:
+                ready.synchronize() if hasattr(ready, "synchronize") else ready.wait()
+            by_tile = np.zeros(p.num_tiles, dtype=np.float32)
+            by_tile[p.order] = host.numpy()
+            p.update(by_tile)
 
     def finish(self):
         """Waits for every exchange still in flight; returns the most recent frame on rank 0."""
@@ -222,6 +257,13 @@ class DistributedRenderer:
                 w.wait()
             self.pending[slot] = []
         return self.frame if self.rank == 0 else None
+
+    def settle(self):
+        """Applies every cost update still on its way, whatever frame it was due at (all ranks must call it at the
+        same point): for callers that want the split the measured costs lead to before they go on."""
+        for k in range(len(self._cost_updates)):
+            self._cost_updates[k] = (self.frame_no, ) + self._cost_updates[k][1:]
+        self._apply_cost_updates()
 
     def _scatter_torch(self, tiles, tile_ids, frame):
         p = self.plan
@@ -326,6 +368,8 @@ class DistributedRenderer:
         Per-tile costs are only measured on the frames whose costs are used: the one before a rebalance,
         or when want_cost is set (render_tiles gets cost=None otherwise)."""
         p = self.plan
+        self._apply_cost_updates()
+        self.last_split = [int(x) for x in p.begin]  # the split this frame is rendered with
         b0, b1 = int(p.begin[self.rank]), int(p.begin[self.rank + 1])
         rebalance_now = bool(self.rebalance_every) and self.frames_since_rebalance + 1 >= self.rebalance_every
         cost = self.cost[b0:b1] if (want_cost or rebalance_now) else None
@@ -376,17 +420,22 @@ class DistributedRenderer:
         self.frames_since_rebalance += 1
         if rebalance_now:
             self.frames_since_rebalance = 0
-            full = self.cost.to(torch.float32)
+            full = self.cost.to(torch.float32)  # a copy: the run's entries are zeroed below
+            ready = None
             if self.world > 1:
                 if self.stage_through_host:
                     full = full.cpu()
-                dist.all_reduce(full)  # every rank contributes its run; all ranks get the whole vector
-            cost_v = full.cpu().numpy()
-            by_tile = np.zeros(p.num_tiles, dtype=np.float32)
-            by_tile[p.order] = cost_v
+                dist.all_reduce(full)  # every rank contributes its run; all ranks get the whole vector (stream-ordered on GPUs)
+            if full.is_cuda:
+                host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
+                host.copy_(full, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+            else:
+                host = full
             if b1 > b0:
                 self.cost[b0:b1].zero_()  # the next run may start elsewhere: leave no stale costs behind
-            p.update(by_tile)
+            self._cost_updates.append((self.frame_no + self.cost_lag - 1, host, ready))
         return self.frame if self.rank == 0 else None
 
     def rays_last_frame(self):
@@ -404,6 +453,11 @@ def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args, cost_kind=
     Cornell box costs ten times one to its ceiling -- or "rays", the number of rays traced, for counting."""
     def fn(tile_ids, out, cost):
         args = frame_args() if callable(frame_args) else dict(frame_args)
+        if args.get("frames", 0) != 0:
+            # the running mean reads the pixel's previous value (renderer.cu:375-387): with frame buffers in
+            # rotation and bands that change owner between frames that value is another frame's, or another rank's
+            raise ValueError("rendering across GPUs takes frames == 0 only (every frame overwrites, as after a camera move); "
+                             "accumulate on one GPU, or average the assembled frames on rank 0")
         ptr = None if cost is None else C.c_void_p(cost.data_ptr())
         # the launch goes onto torch's current stream of the output's device: the exchange (RCCL) and the torch
         # operations on `out` and `cost` that follow are ordered against that stream

@@ -70,16 +70,25 @@ def _worker(rank, world, port, out_path, layout):
     assert dr.bands == (layout == "bands")
     results = {}
     splits = []
-    for step, seed in enumerate((21, 22, 23)):
+    # frames 0 .. lag: uniform split until the first frame's costs arrive (they decide the split `cost_lag` frames
+    # later); then the camera moves: uniform again
+    seeds = list(range(21, 21 + dr.cost_lag + 2))
+    for step, seed in enumerate(seeds):
         state["seed"] = seed
-        if step == 2:
+        if step == len(seeds) - 1:
             dr.camera_moved()  # back to the uniform split
-        splits.append([int(x) for x in dr.plan.begin])
         dr.render_frame()
+        splits.append(dr.last_split)
         frame = dr.finish()
         if rank == 0:
             ref = o.render(W, H, seed=seed, frames=0, max_bounces=2, threads=2)["screen"]
             results[f"equal{step}"] = bool(np.array_equal(frame.numpy().view(np.uint32), ref.view(np.uint32)))
+    results["steps"] = len(seeds)
+    results["lag"] = dr.cost_lag
+    # every rank derived the same splits
+    every = [None] * world
+    dist.all_gather_object(every, splits)
+    assert all(e == every[0] for e in every)
     # frames started back to back: the exchange of one frame is still in flight while the next one renders
     for seed in (31, 32, 33):
         state["seed"] = seed
@@ -98,9 +107,9 @@ def _worker(rank, world, port, out_path, layout):
         state["slow_rank"] = 1
         cal = dr.calibrate(frames=2)
         state["slow_rank"] = -1
-        begins = [None, None]
+        begins = [None] * world
         dist.all_gather_object(begins, [int(x) for x in dr.plan.begin])
-        assert begins[0] == begins[1]
+        assert all(b == begins[0] for b in begins)
         state["seed"] = 41
         dr.camera_moved()  # costs back to uniform; the shares stay
         dr.render_frame()
@@ -119,22 +128,27 @@ def _worker(rank, world, port, out_path, layout):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("layout", ["tiles", "bands"])
-def test_two_rank_frame_assembly(tmp_path, layout):
+@pytest.mark.parametrize("world,layout", [(2, "tiles"), (2, "bands"), (4, "bands")])
+def test_frame_assembly_across_ranks(tmp_path, world, layout):
     out = str(tmp_path / "res.pt")
-    mp.start_processes(_worker, args=(2, _free_port(), out, layout), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, _free_port(), out, layout), nprocs=world, join=True, start_method="spawn")
     res = torch.load(out)
-    assert res["equal0"] and res["equal1"] and res["equal2"] and res["equal_pipelined"]
-    s0, s1, s2 = res["splits"]
-    n = s0[-1]
-    assert s0[0] == 0 and s0[1] in (n // 2, (n + 1) // 2) and s0[2] == n and s2 == s0   # uniform at start and after the camera move
-    assert s1 != s0 and s1[0] == 0 and s1[-1] == n    # rebalanced from the first frame's costs
+    steps, lag = res["steps"], res["lag"]
+    assert all(res[f"equal{k}"] for k in range(steps)) and res["equal_pipelined"]
+    splits = res["splits"]
+    n = splits[0][-1]
+    uniform = splits[0]
+    assert uniform[0] == 0 and uniform[-1] == n and len(uniform) == world + 1
+    assert max(np.diff(uniform)) - min(np.diff(uniform)) <= 1          # equal shares at the start
+    assert all(s == uniform for s in splits[:lag])                      # until the first frame's costs arrive
+    assert splits[lag] != uniform and splits[lag][0] == 0 and splits[lag][-1] == n   # rebalanced from the first frame's costs
+    assert splits[-1] == uniform                                        # and uniform again after the camera move
     if layout == "bands":
         assert res["equal_weighted"]
         w = res["weights"]
         assert abs(sum(w) - 1.0) < 1e-5 and w[1] < w[0]
         ws = res["weighted_split"]
-        assert ws[0] == 0 and ws[2] == n and ws[1] > n // 2   # the slow rank renders fewer bands
+        assert ws[0] == 0 and ws[-1] == n and (ws[2] - ws[1]) == min(np.diff(ws)) and (ws[2] - ws[1]) < (ws[1] - ws[0])   # the slow rank renders the fewest bands
 
 
 def test_single_rank_path_without_process_group():
