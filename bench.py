@@ -166,6 +166,9 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
         torch.cuda.synchronize()
         same = bool(torch.equal(full.view(torch.int32), dr.frame.view(torch.int32)))
         print(f"[check {w.name}] assembled frame equals single-GPU frame: {same}; split {[int(x) for x in dr.plan.begin]}", file=sys.stderr)
+        if not same:
+            rows = torch.nonzero((full.view(torch.int32) != dr.frame.view(torch.int32)).any(dim=2).any(dim=1)).flatten().tolist()
+            print(f"[check {w.name}] differing rows: {len(rows)}, first {rows[:8]}, last {rows[-8:]}; split used by the frame {dr.last_split}", file=sys.stderr)
         del full
     # rays of the timed frames, counted afterwards: the same seeds and cameras once more with per-tile ray
     # counts switched on (the total does not depend on how the frame is split)

@@ -339,12 +339,22 @@ int acr_host_partition_tiles_weighted(const uint32_t *order, const float *cost, 
 	for (uint32_t k = 1; k < parts; k++) {
 		wrun += weights ? double(weights[k - 1]) : 1.0;
 		const double target = total * wrun / wsum;
+		auto costAt = [&](uint32_t i) { return cost ? double(cost[order[i]] > 0 ? cost[order[i]] : 0) : 1.0; };
 		while (at < num_tiles) {
-			const double c = cost ? double(cost[order[at]] > 0 ? cost[order[at]] : 0) : 1.0;
+			const double c = costAt(at);
 			// stop before the tile that would overshoot the target by more than it undershoots
 			if (run + c * 0.5 > target) break;
 			run += c;
 			at++;
+		}
+		if (num_tiles >= parts) {
+			// no part with a share is left without a tile (a rank with nothing to render would sit out the frame),
+			// and enough tiles stay for the parts that follow
+			const bool hasShare = !weights || weights[k - 1] > 0;
+			while (hasShare && at < begin_out[k - 1] + 1) run += costAt(at++);
+			uint32_t follow = 0; // parts after this cut that have a share
+			for (uint32_t j = k; j < parts; j++) follow += (!weights || weights[j] > 0) ? 1u : 0u;
+			while (at > num_tiles - follow) run -= costAt(--at);
 		}
 		begin_out[k] = at;
 	}

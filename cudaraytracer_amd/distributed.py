@@ -19,7 +19,8 @@ The renderer itself is passed in as a callable so that the same code runs on
 CPU ranks in tests:
 
     render_tiles(tile_ids, out, cost) -> None
-        tile_ids : 1-D int array of the tiles this rank renders, in order
+        tile_ids : 1-D int array of the tiles this rank renders, in order; may be empty (the call is made on every
+                   frame so that state the callable keeps per frame, like seeds and cameras, advances on all ranks)
         out      : torch tensor [len(tile_ids), tile_h * tile_w, 4] float32 to fill
         cost     : torch tensor [len(tile_ids)] int32 to fill (any positive cost measure), or None when
                    this frame's costs are not needed
@@ -382,8 +383,7 @@ class DistributedRenderer:
             flat = self.frames[slot].view(-1, 4)
             px0, px1 = self._band_pixels(b0, b1)
             out = flat[px0:px1]
-            if b1 > b0:
-                self.render_tiles(p.order[b0:b1], out, cost)
+            self.render_tiles(p.order[b0:b1], out, cost)  # also with an empty run: the callable keeps per-frame state (seeds, cameras)
             self._last_slot = slot
             if self.world > 1 and not self._exchange_off:
                 self._exchange(slot)
@@ -391,8 +391,7 @@ class DistributedRenderer:
             # rank 0 keeps its run at its Z position; other ranks use the front of their buffer
             at = b0 if self.rank == 0 else 0
             out = self.tiles[at:at + (b1 - b0)]
-            if b1 > b0:
-                self.render_tiles(p.order[b0:b1], out, cost)
+            self.render_tiles(p.order[b0:b1], out, cost)
             if self.world > 1:
                 ops, staged = [], {}
                 if self.rank == 0:
@@ -458,6 +457,8 @@ def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args, cost_kind=
             # rotation and bands that change owner between frames that value is another frame's, or another rank's
             raise ValueError("rendering across GPUs takes frames == 0 only (every frame overwrites, as after a camera move); "
                              "accumulate on one GPU, or average the assembled frames on rank 0")
+        if len(tile_ids) == 0:
+            return  # nothing of this frame is this rank's (an empty list would mean "the whole frame" to the C ABI)
         ptr = None if cost is None else C.c_void_p(cost.data_ptr())
         # the launch goes onto torch's current stream of the output's device: the exchange (RCCL) and the torch
         # operations on `out` and `cost` that follow are ordered against that stream

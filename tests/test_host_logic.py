@@ -80,6 +80,16 @@ def test_partition_uniform_and_weighted():
     # zero / negative / NaN-free costs are clamped, not trusted
     b4 = D.partition(order, np.zeros(128, np.float32), 4)
     assert b4[0] == 0 and b4[-1] == 128
+    # no part with a share is left without a tile, wherever the cost sits and however small the share
+    bands = np.arange(68, dtype=np.uint32)
+    for hot in (0, 33, 67):
+        c = np.full(68, 1e-3, np.float32)
+        c[hot] = 1e6
+        for w in (None, [0.9, 0.03, 0.03, 0.04], [0.97, 0.01, 0.01, 0.01]):
+            b5 = D.partition(bands, c, 4, w).astype(int)
+            assert b5[0] == 0 and b5[-1] == 68 and np.all(np.diff(b5) >= 1), (hot, w, b5)
+    b6 = D.partition(bands, None, 4, [1.0, 0.0, 1.0, 1.0]).astype(int)   # a part with no share may stay empty
+    assert b6[0] == 0 and b6[-1] == 68 and b6[2] - b6[1] <= 1 and np.all(np.diff(b6) >= 0)
 
 
 def test_partition_rejects_bad_input():
@@ -157,8 +167,10 @@ def test_shares_from_measured_times():
         per = frame_times(w2)
         assert per.max() / per.min() < 1.02           # the affine model is exact here: every rank takes the same time
         assert frame_times(w2).max() < frame_times(np.full(world, 1.0 / world)).max()   # better than equal shares
-    # a rank that cannot send at all ends up with nothing, the others share the frame
+    # a rank that all but cannot send is held at one band (and the caller is warned), the others share the frame
+    import pytest
     b, t = measure([17.0] * 4)
     t[2, 1] = 10.0
-    w = solve_shares([(b, t)], 68)
-    assert w[2] < 1e-3 and abs(w.sum() - 1) < 1e-9
+    with pytest.warns(RuntimeWarning, match="less than one band"):
+        w = solve_shares([(b, t)], 68)
+    assert 0.9 / 68 < w[2] < 1.1 / 68 and abs(w.sum() - 1) < 1e-9 and w[2] == w.min()
