@@ -37,6 +37,38 @@ namespace acr
 		math::vec3 min, max;
 	};
 
+	// Sum and bounds of a sequence of points (or boxes), folded strictly in the order given: the results feed the
+	// BIH build, which has to come out bit-identical to the reference's, so the order of the float operations is
+	// fixed -- sum += p, and min / max with the running value as first or as second operand, whichever the
+	// reference writes at that place (geometry.cu:22-29, scene.cu:349-350,386-388).
+	struct PointFold
+	{
+		math::vec3 sum = math::vec3(0, 0, 0);
+		BoundingBox box = {math::vec3(FLT_MAX, FLT_MAX, FLT_MAX), math::vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX)};
+		size_t count = 0;
+
+		void runningFirst(const math::vec3 &p) // min(running, p)
+		{
+			sum += p;
+			box.min = math::min(box.min, p);
+			box.max = math::max(box.max, p);
+			count++;
+		}
+		void runningSecond(const math::vec3 &p) // min(p, running)
+		{
+			sum += p;
+			box.min = math::min(p, box.min);
+			box.max = math::max(p, box.max);
+			count++;
+		}
+		void enclose(const BoundingBox &b) // running value first
+		{
+			box.min = math::min(box.min, b.min);
+			box.max = math::max(box.max, b.max);
+		}
+		math::vec3 mean() const { return sum / float(count); }
+	};
+
 	struct Face // geometry.h:91-121
 	{
 		uint32_t indices[3];

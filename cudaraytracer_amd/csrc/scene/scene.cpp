@@ -88,63 +88,70 @@ namespace acr
 			hLights.emplace_back(scene.lights[i]);
 	}
 
-	// scene.cu:122-152
+	// The node hierarchy becomes the object list (scene.cu:122-202): one Object per node, numbered in depth-first
+	// pre-order, children in the order the import lists them; lights and the camera are moved to world space by the
+	// node that carries their name; the objects with meshes go into the BIH.
 	void Scene::loadObjects(const acr_import_scene &scene, const std::string &camName, std::vector<Light> &hLights, std::vector<Mesh> &hMeshes,
 	                        size_t sceneBihDepth)
 	{
-		std::vector<std::vector<uint32_t>> childLists(scene.num_nodes);
-		for (uint32_t i = 0; i < scene.num_nodes; i++)
-			if (scene.nodes[i].parent >= 0) childLists[size_t(scene.nodes[i].parent)].push_back(i);
+		// import nodes refer to their parent; the walk needs each node's children
+		std::vector<std::vector<uint32_t>> childNodes(scene.num_nodes);
+		for (uint32_t n = 0; n < scene.num_nodes; n++)
+			if (scene.nodes[n].parent >= 0) childNodes[size_t(scene.nodes[n].parent)].push_back(n);
 
 		std::vector<Object> objs;
-		rootIndex = scene.num_nodes ? loadObject(scene, 0, nullptr, objs, camName, hLights, hMeshes, childLists) : -1;
-
-		boundingBox.max = math::vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-		boundingBox.min = math::vec3(FLT_MAX, FLT_MAX, FLT_MAX);
-
-		// only nodes that carry meshes take part in the BIH (scene.cu:131-143)
-		std::vector<Object> filteredObjs;
-		for (const Object &o : objs)
-			if (o.meshes.size() > 0) filteredObjs.push_back(o);
-
-		for (size_t i = 0; i < filteredObjs.size(); i++) {
-			boundingBox.max = math::max(boundingBox.max, filteredObjs[i].boundingBox.max);
-			boundingBox.min = math::min(boundingBox.min, filteredObjs[i].boundingBox.min);
+		std::vector<uint32_t> nodeOf;               // import node of each object
+		std::vector<std::vector<int>> childrenOf;   // object numbers of each object's children
+		struct Pending { uint32_t node; int parent; };
+		std::vector<Pending> todo;
+		if (scene.num_nodes) todo.push_back({0u, -1});
+		while (!todo.empty()) {
+			const Pending at = todo.back();
+			todo.pop_back();
+			const int number = int(objs.size());
+			math::mat4 parentGlobal; // a copy: the list may move while it grows
+			if (at.parent >= 0) parentGlobal = objs[size_t(at.parent)].globalTransform;
+			objs.emplace_back(scene, scene.nodes[at.node], number, at.parent, at.parent >= 0 ? &parentGlobal : nullptr, hMeshes);
+			nodeOf.push_back(at.node);
+			childrenOf.emplace_back();
+			if (at.parent >= 0) childrenOf[size_t(at.parent)].push_back(number);
+			// last child first onto the stack: the first child is the next node visited
+			for (size_t k = childNodes[at.node].size(); k-- > 0;)
+				todo.push_back({childNodes[at.node][k], number});
 		}
+		for (size_t i = 0; i < objs.size(); i++)
+			objs[i].children = vector<int>(childrenOf[i]);
+		rootIndex = objs.empty() ? -1 : 0;
 
-		objects = BIH<Object>(filteredObjs, boundingBox, nullptr, sceneBihDepth);
-	}
-
-	// scene.cu:155-202
-	int Scene::loadObject(const acr_import_scene &scene, uint32_t nodeIdx, const Object *parent, std::vector<Object> &objs, const std::string &camName,
-	                      std::vector<Light> &hLights, std::vector<Mesh> &hMeshes, const std::vector<std::vector<uint32_t>> &childLists)
-	{
-		const acr_import_node &node = scene.nodes[nodeIdx];
-		Object tmp(scene, node, int(objs.size()), parent, hMeshes);
-		objs.push_back(tmp);
-		const int i = tmp.index;
-
-		// lights and the camera are tied to their nodes by name (scene.cu:174-191);
-		// of several lights with one name the first is the one the map keeps (scene.cu:117)
-		for (uint32_t li = 0; li < scene.num_lights; li++) {
-			if (sameName(scene.lights[li].name, node.name)) {
-				Light &l = hLights[li];
-				l.position = math::translate(objs[size_t(i)].globalTransform, l.position);
-				l.direction = math::translaten(tmp.globalNormalTransform, l.direction);
+		// Lights and the camera are tied to nodes by name (scene.cu:174-191).  Of several lights with one name the first
+		// is the one the reference's name map keeps (scene.cu:117); nodes are taken in the order they were visited.
+		for (size_t i = 0; i < objs.size(); i++) {
+			const acr_import_node &node = scene.nodes[nodeOf[i]];
+			const Object &o = objs[i];
+			for (uint32_t li = 0; li < scene.num_lights; li++) {
+				if (!sameName(scene.lights[li].name, node.name)) continue;
+				hLights[li].position = math::translate(o.globalTransform, hLights[li].position);
+				hLights[li].direction = math::translaten(o.globalNormalTransform, hLights[li].direction);
 				break;
 			}
-		}
-		if (std::string(node.name, strnlen(node.name, 64)) == camName) {
-			camera.position = math::translate(tmp.globalTransform, camera.position);
-			camera.forward = math::translaten(tmp.globalNormalTransform, camera.forward);
-			camera.up = math::translaten(tmp.globalNormalTransform, camera.up);
+			if (std::string(node.name, strnlen(node.name, 64)) == camName) {
+				camera.position = math::translate(o.globalTransform, camera.position);
+				camera.forward = math::translaten(o.globalNormalTransform, camera.forward);
+				camera.up = math::translaten(o.globalNormalTransform, camera.up);
+			}
 		}
 
-		std::vector<int> children;
-		for (uint32_t c : childLists[nodeIdx])
-			children.push_back(loadObject(scene, c, &tmp, objs, camName, hLights, hMeshes, childLists));
-		objs[size_t(i)].children = vector<int>(children);
-		return i;
+		// only nodes that carry meshes take part in the BIH (scene.cu:131-143); its root box is the union of
+		// their world boxes (scene.cu:145-149: max first, then min, running value as first operand)
+		std::vector<Object> withMeshes;
+		PointFold world;
+		for (const Object &o : objs) {
+			if (o.meshes.size() == 0) continue;
+			withMeshes.push_back(o);
+			world.enclose(o.boundingBox);
+		}
+		boundingBox = world.box;
+		objects = BIH<Object>(withMeshes, boundingBox, nullptr, sceneBihDepth);
 	}
 
 	// scene.cu:303-330
@@ -164,60 +171,49 @@ namespace acr
 		}
 	}
 
-	// scene.cu:332-357: the eight corners go through the global transform one by one
+	// World-space AABB of a local-space box (scene.cu:332-357): its eight corners go through the global transform
+	// one by one -- x from bit 2 of the corner number, y from bit 1, z from bit 0 -- and are folded with the new
+	// corner as first operand of min / max.
 	BoundingBox Object::transformBoundingBox(BoundingBox bb) const
 	{
-		BoundingBox bounds;
-		bounds.max = math::vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-		bounds.min = math::vec3(FLT_MAX, FLT_MAX, FLT_MAX);
-		const float coords[6] = {bb.min.x, bb.min.y, bb.min.z, bb.max.x, bb.max.y, bb.max.z};
-		for (int i = 0; i < 8; i++) {
-			const int xi = 3 * (i >> 2);
-			const int yi = 3 * ((i >> 1) & 1) + 1;
-			const int zi = 3 * (i & 1) + 2;
-			const math::vec3 localVertex(coords[xi], coords[yi], coords[zi]);
-			const math::vec3 globalVertex = math::translate(globalTransform, localVertex);
-			bounds.min = math::min(globalVertex, bounds.min);
-			bounds.max = math::max(globalVertex, bounds.max);
+		const math::vec3 *end[2] = {&bb.min, &bb.max};
+		PointFold fold;
+		for (unsigned corner = 0; corner < 8; corner++) {
+			const math::vec3 local(end[(corner >> 2) & 1u]->x, end[(corner >> 1) & 1u]->y, end[corner & 1u]->z);
+			fold.runningSecond(math::translate(globalTransform, local));
 		}
-		return bounds;
+		return fold.box;
 	}
 
-	// scene.cu:359-405
-	Object::Object(const acr_import_scene &scene, const acr_import_node &node, int idx, const Object *parent, const std::vector<Mesh> &hMeshes)
-		: index(idx), parentIndex(parent ? parent->index : -1)
+	// scene.cu:359-405.  parentGlobal: the parent object's global transform, null for the root.
+	Object::Object(const acr_import_scene &scene, const acr_import_node &node, int idx, int parentIdx, const math::mat4 *parentGlobal,
+	               const std::vector<Mesh> &hMeshes)
+		: index(idx), parentIndex(parentIdx), centroid(0, 0, 0)
 	{
+		// placement: global = parent's global * local, and the three matrices derived from it (scene.cu:363-367)
 		localTransform = toMat4(node.transform);
-		globalTransform = parent ? parent->globalTransform * localTransform : localTransform;
+		globalTransform = parentGlobal ? *parentGlobal * localTransform : localTransform;
 		globalInverseTransform = math::inverse(globalTransform);
 		globalNormalTransform = math::transpose(math::inverse(math::toMat3(globalTransform)));
 		globalInverseNormalTransform = math::inverse(globalNormalTransform);
 
-		std::vector<int> objMeshes;
-		for (uint32_t k = 0; k < node.mesh_count; k++)
-			objMeshes.push_back(int(scene.node_mesh_ids[node.mesh_begin + k]));
-		centroid = math::vec3(0, 0, 0);
-		boundingBox.min = math::vec3(0, 0, 0);
-		boundingBox.max = math::vec3(0, 0, 0);
+		// the node's meshes: numbers into the scene's mesh list
+		const uint32_t *ids = scene.node_mesh_ids + node.mesh_begin;
+		const std::vector<int> mine(ids, ids + node.mesh_count);
+		meshes = vector<int>(mine);
+		boundingBox.min = boundingBox.max = math::vec3(0, 0, 0);
+		if (mine.empty())
+			return;
 
-		if (objMeshes.size() > 0) {
-			math::vec3 minBound(FLT_MAX, FLT_MAX, FLT_MAX);
-			math::vec3 maxBound(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-			math::vec3 sumCentroids(0, 0, 0);
-			for (size_t i = 0; i < objMeshes.size(); i++) {
-				const Mesh &m = hMeshes[size_t(objMeshes[i])];
-				sumCentroids += m.centroid;
-				minBound = math::min(minBound, m.boundingBox.min);
-				maxBound = math::max(maxBound, m.boundingBox.max);
-			}
-			BoundingBox localBoundingBox;
-			localBoundingBox.min = minBound;
-			localBoundingBox.max = maxBound;
-			boundingBox = transformBoundingBox(localBoundingBox);
-
-			const math::vec3 avgCentroid = sumCentroids / float(objMeshes.size());
-			centroid = math::translate(globalTransform, avgCentroid);
+		// extent: the local box around the meshes' boxes, taken to world space corner by corner; centroid: the mean of
+		// the meshes' centroids, taken to world space (scene.cu:372-400)
+		PointFold local;
+		for (int m : mine) {
+			local.sum += hMeshes[size_t(m)].centroid;
+			local.count++;
+			local.enclose(hMeshes[size_t(m)].boundingBox);
 		}
-		meshes = vector<int>(objMeshes);
+		boundingBox = transformBoundingBox(local.box);
+		centroid = math::translate(globalTransform, local.mean());
 	}
 } // namespace acr

@@ -23,7 +23,9 @@ namespace acr
 	public:
 		Object() : index(0), parentIndex(-1) {}
 		// the reference's Object(const aiNode*, int, Object*, host_vector<Mesh>&) (scene.cu:359-405)
-		Object(const acr_import_scene &scene, const acr_import_node &node, int index, const Object *parent, const std::vector<Mesh> &hMeshes);
+		// parentGlobal: the parent's global transform, null for the root
+		Object(const acr_import_scene &scene, const acr_import_node &node, int index, int parentIndex, const math::mat4 *parentGlobal,
+		       const std::vector<Mesh> &hMeshes);
 
 		int index;
 		int parentIndex;
@@ -127,8 +129,6 @@ namespace acr
 		void loadMeshes(const acr_import_scene &scene, std::vector<Mesh> &hMeshes, size_t meshBihDepth);
 		void loadObjects(const acr_import_scene &scene, const std::string &camName, std::vector<Light> &hLights, std::vector<Mesh> &hMeshes,
 		                 size_t sceneBihDepth);
-		int loadObject(const acr_import_scene &scene, uint32_t node, const Object *parent, std::vector<Object> &objs, const std::string &camName,
-		               std::vector<Light> &hLights, std::vector<Mesh> &hMeshes, const std::vector<std::vector<uint32_t>> &childLists);
 
 		BIH<Object> objects; // scene.h:117
 		mutable SceneArrays *arrays = nullptr;
