@@ -124,6 +124,9 @@ HIP_SYMBOLS = {
     "acr_hip_framebuffer": (C.c_void_p, [C.c_void_p]),
     "acr_hip_pixel_map": (C.c_void_p, [C.c_void_p]),
     "acr_hip_path_keys": (C.c_void_p, [C.c_void_p]),
+    "acr_hip_path_votes": (C.c_void_p, [C.c_void_p]),
+    "acr_hip_vote_paths": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
+    "acr_hip_vote_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "acr_hip_sort_pixel_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "acr_hip_scatter_tiles": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_void_p]),

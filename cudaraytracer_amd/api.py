@@ -233,6 +233,14 @@ class HipCore:
         """pixel_values <- pixel numbers stably sorted by traversal-path key (device pointers, asynchronous)"""
         self._check(self._lib.acr_hip_sort_pixel_map(self._h, path_keys_dev, pixel_values_dev, num_pixels), "acr_hip_sort_pixel_map")
 
+    def vote_paths(self, path_keys_dev, votes_dev, num_pixels, reset):
+        """the reference's PathAggregate::set (reset) / ::add for every pixel (device pointers, asynchronous)"""
+        self._check(self._lib.acr_hip_vote_paths(self._h, path_keys_dev, votes_dev, num_pixels, 1 if reset else 0), "acr_hip_vote_paths")
+
+    def vote_keys(self, votes_dev, path_keys_dev, num_pixels):
+        """majority key of every pixel's vote table (device pointers, asynchronous)"""
+        self._check(self._lib.acr_hip_vote_keys(self._h, votes_dev, path_keys_dev, num_pixels), "acr_hip_vote_keys")
+
     def scatter_tiles(self, tiles_dev, tile_ids, tile_w, tile_h, width, height, frame_dev):
         ids = np.ascontiguousarray(tile_ids, dtype=np.uint32)
         self._check(self._lib.acr_hip_scatter_tiles(self._h, tiles_dev, ids.ctypes.data_as(_capi.c_u32_p), len(ids),

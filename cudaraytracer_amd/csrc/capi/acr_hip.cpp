@@ -62,6 +62,7 @@ struct acr_hip_ctx
 	float *hitT = nullptr;
 	int32_t *pixelValues = nullptr;
 	uint64_t *pathKeys = nullptr;
+	int32_t *pathVotes = nullptr; // [64][width * height], allocated on first request (acr_hip_path_votes)
 
 	// per-launch scratch
 	unsigned long long *counters = nullptr; // device [kCounterSlots][4]
@@ -387,6 +388,7 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->hitT);
 	(void)hipFree(ctx->pixelValues);
 	(void)hipFree(ctx->pathKeys);
+	(void)hipFree(ctx->pathVotes);
 	(void)hipFree(ctx->counters);
 	(void)hipFree(ctx->redoCount);
 	(void)hipFree(ctx->redoList);
@@ -672,6 +674,7 @@ int acr_hip_resize(acr_hip_ctx *ctx, uint32_t width, uint32_t height)
 	(void)hipFree(ctx->hitT); ctx->hitT = nullptr;
 	(void)hipFree(ctx->pixelValues); ctx->pixelValues = nullptr;
 	(void)hipFree(ctx->pathKeys); ctx->pathKeys = nullptr;
+	(void)hipFree(ctx->pathVotes); ctx->pathVotes = nullptr;
 	ctx->width = ctx->height = 0;
 	const size_t n = size_t(width) * height;
 	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->screen), n * sizeof(float4)));
@@ -1046,6 +1049,39 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 void *acr_hip_framebuffer(acr_hip_ctx *ctx) { return ctx ? ctx->screen : nullptr; }
 int32_t *acr_hip_pixel_map(acr_hip_ctx *ctx) { return ctx ? ctx->pixelValues : nullptr; }
 uint64_t *acr_hip_path_keys(acr_hip_ctx *ctx) { return ctx ? ctx->pathKeys : nullptr; }
+
+int32_t *acr_hip_path_votes(acr_hip_ctx *ctx)
+{
+	if (!ctx || !ctx->width) return nullptr;
+	if (!ctx->pathVotes) {
+		const size_t bytes = size_t(64) * ctx->width * ctx->height * sizeof(int32_t);
+		if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&ctx->pathVotes), bytes) != hipSuccess) {
+			ctx->pathVotes = nullptr;
+			fail(ctx, ACR_ERR_HIP, "no memory for %zu bytes of path votes", bytes);
+			return nullptr;
+		}
+		if (hipMemsetAsync(ctx->pathVotes, 0, bytes, ctx->stream) != hipSuccess) return nullptr;
+	}
+	return ctx->pathVotes;
+}
+
+int acr_hip_vote_paths(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *votes_dev, uint32_t num_pixels, int reset)
+{
+	if (!ctx || !path_keys_dev || !votes_dev) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (num_pixels == 0) return ACR_OK;
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, acr_dev_launch_vote_paths(path_keys_dev, votes_dev, num_pixels, reset, ctx->stream));
+	return ACR_OK;
+}
+
+int acr_hip_vote_keys(acr_hip_ctx *ctx, const int32_t *votes_dev, uint64_t *path_keys_dev, uint32_t num_pixels)
+{
+	if (!ctx || !path_keys_dev || !votes_dev) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (num_pixels == 0) return ACR_OK;
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ACR_HIP_TRY(ctx, acr_dev_launch_vote_keys(votes_dev, path_keys_dev, num_pixels, ctx->stream));
+	return ACR_OK;
+}
 
 int acr_hip_sort_pixel_map(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *pixel_values_dev, uint32_t num_pixels)
 {

@@ -1972,6 +1972,44 @@ extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int
 	return p->path_keys ? launchRender<true>(p, ldsMode, fast, grid, ldsBytes, stream) : launchRender<false>(p, ldsMode, fast, grid, ldsBytes, stream);
 }
 
+// PathAggregate (bih.h:29-66) for every pixel, the counters plane by plane (votes[bit * n + pixel]) so that the
+// work-items of a wave touch consecutive addresses.  reset: PathAggregate::set (renderer.cu:386), else ::add
+// (renderer.cu:380); counter i belongs to bit i of the path, so that an aggregate of one path converts back to it.
+__global__ void __launch_bounds__(256) votePathsKernel(const uint64_t *__restrict__ keys, int32_t *__restrict__ votes, uint32_t n, int reset)
+{
+	const uint32_t px = blockIdx.x * 256u + threadIdx.x;
+	if (px >= n) return;
+	uint64_t bits = keys[px];
+#pragma unroll 8
+	for (uint32_t i = 0; i < 64; i++) {
+		const int32_t vote = (bits & 1u) ? -1 : 1;
+		int32_t *w = votes + size_t(i) * n + px;
+		*w = reset ? vote : *w + vote;
+		bits >>= 1;
+	}
+}
+// PathAggregate::operator uint64_t (bih.h:55-65): bit i set where counter i is negative
+__global__ void __launch_bounds__(256) voteKeysKernel(const int32_t *__restrict__ votes, uint64_t *__restrict__ keys, uint32_t n)
+{
+	const uint32_t px = blockIdx.x * 256u + threadIdx.x;
+	if (px >= n) return;
+	uint64_t path = 0;
+#pragma unroll 8
+	for (uint32_t i = 0; i < 64; i++)
+		path |= uint64_t(votes[size_t(i) * n + px] < 0) << i;
+	keys[px] = path;
+}
+extern "C" hipError_t acr_dev_launch_vote_paths(const uint64_t *keys, int32_t *votes, uint32_t n, int reset, hipStream_t stream)
+{
+	hipLaunchKernelGGL(votePathsKernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, votes, n, reset);
+	return hipGetLastError();
+}
+extern "C" hipError_t acr_dev_launch_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n, hipStream_t stream)
+{
+	hipLaunchKernelGGL(voteKeysKernel, dim3((n + 255) / 256), dim3(256), 0, stream, votes, keys, n);
+	return hipGetLastError();
+}
+
 // values[i] = i (thrust::sequence at renderer.cu:137)
 __global__ void __launch_bounds__(256) iotaKernel(int32_t *values, uint32_t n)
 {

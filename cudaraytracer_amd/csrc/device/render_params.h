@@ -96,6 +96,8 @@ namespace dev
 extern "C" {
 hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream);
+hipError_t acr_dev_launch_vote_paths(const uint64_t *keys, int32_t *votes, uint32_t n, int reset, hipStream_t stream);
+hipError_t acr_dev_launch_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n, hipStream_t stream);
 // order[0..n) = the numbers 0..n-1, the ones with the largest cost[] first (256 cost classes)
 hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream);
 hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);

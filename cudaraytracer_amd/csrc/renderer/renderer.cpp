@@ -90,13 +90,20 @@ namespace acr
 		f.max_bounces = maxBounces;
 		f.collect_stats = collectStats ? 1u : 0u;
 		const bool resort = adaptive && (framesNoMove + 1) % pixelMapFrameMod == 0; // renderer.cu:457
+		int32_t *votes = nullptr;
 		if (adaptive) {
 			f.pixel_values_dev = acr_hip_pixel_map(ctx);                // renderer.cu:343-355
-			if (resort) f.path_keys_dev = acr_hip_path_keys(ctx);       // renderer.cu:380,386
+			f.path_keys_dev = acr_hip_path_keys(ctx);                   // the Path of renderer.cu:341,372
+			votes = acr_hip_path_votes(ctx);
+			if (!votes) check(ACR_ERR_HIP, "acr_hip_path_votes");
 		}
 		check(acr_hip_render(ctx, &f, nullptr, nullptr, nullptr), "acr_hip_render");
-		if (resort) // renderer.cu:459-460
+		if (adaptive) // paths[...].set(path) on the first frame after a move, .add(path) afterwards (renderer.cu:380,386)
+			check(acr_hip_vote_paths(ctx, acr_hip_path_keys(ctx), votes, dim.x * dim.y, framesNoMove == 0), "acr_hip_vote_paths");
+		if (resort) { // renderer.cu:459-460: the aggregates as keys, then the sort
+			check(acr_hip_vote_keys(ctx, votes, acr_hip_path_keys(ctx), dim.x * dim.y), "acr_hip_vote_keys");
 			check(acr_hip_sort_pixel_map(ctx, acr_hip_path_keys(ctx), acr_hip_pixel_map(ctx), dim.x * dim.y), "acr_hip_sort_pixel_map");
+		}
 		check(acr_hip_sync(ctx), "acr_hip_sync"); // cudaDeviceSynchronize (renderer.cu:422)
 		framesNoMove++;
 	}

@@ -46,8 +46,9 @@ namespace acr
 		void setFixedSeed(long long seed) { fixedSeed = seed; } // < 0: rand()
 		void setCollectStats(bool on) { collectStats = on; }
 		// The reference's adaptive assignment (renderer.cu:343-355,391-392,457-461; disabled at its v0, so off by
-		// default): every `every` frames without a camera move the pixel table is re-sorted by the traversal-path keys
-		// of the frame just rendered; a move resets it to the identity.
+		// default): every frame's traversal-path keys are voted into the per-pixel aggregates (bih.h:29-66), every `every`
+		// frames without a camera move the pixel table is re-sorted by the aggregates' majority keys; a move resets
+		// table and aggregates.
 		void setAdaptiveAssignment(bool on, uint32_t every = 60) { adaptive = on; pixelMapFrameMod = every ? every : 60; }
 		void setCamera(const Camera &cam); // places the camera directly; restarts accumulation like a move
 		Camera getCamera() const;

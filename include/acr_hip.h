@@ -292,6 +292,20 @@ uint64_t *acr_hip_path_keys(acr_hip_ctx *ctx);
  * context's stream. */
 int acr_hip_sort_pixel_map(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *pixel_values_dev, uint32_t num_pixels);
 
+/* The reference's per-pixel vote table, PathAggregate (bih.h:29-66; 64 signed counters per aggregate, one per bit
+ * of a path key; all bodies commented out at its v0): the history of traversal paths that the adaptive assignment
+ * sorts by.  acr_hip_vote_paths with reset != 0 is PathAggregate::set for every pixel (the frames == 0 branch,
+ * renderer.cu:386: counter i = bit i of the pixel's key ? -1 : +1), with reset == 0 PathAggregate::add
+ * (renderer.cu:380: counter i += ...).  acr_hip_vote_keys is the conversion back to a key (bih.h:55-65: bit i set where
+ * counter i is negative, i.e. where most frames had it set), the input of acr_hip_sort_pixel_map where the reference
+ * copies pixelKeyData (renderer.cu:459).  Counters are device int32 [64][num_pixels] (votes[bit * num_pixels + pixel]),
+ * indexed by pixel like the keys.  acr_hip_path_votes returns the context-owned table for the size of the last
+ * acr_hip_resize, allocated (256 bytes per pixel) and zeroed on its first call; NULL before acr_hip_resize or when
+ * there is no memory for it.  Device pointers; asynchronous on the context's stream. */
+int32_t *acr_hip_path_votes(acr_hip_ctx *ctx);
+int acr_hip_vote_paths(acr_hip_ctx *ctx, const uint64_t *path_keys_dev, int32_t *votes_dev, uint32_t num_pixels, int reset);
+int acr_hip_vote_keys(acr_hip_ctx *ctx, const int32_t *votes_dev, uint64_t *path_keys_dev, uint32_t num_pixels);
+
 /* Copies compact tiles (as written by a tiled acr_hip_render) into a full
  * [height][width] float4 frame on the same device: the last step after the
  * finished tiles of every GPU have been gathered to GPU 0. */

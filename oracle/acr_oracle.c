@@ -1734,3 +1734,34 @@ int orc_kat(const char *fn, const float *in, float *out)
 	if (!strcmp(fn, "pi")) { out[0] = 3.14159265358979323846264338327950288f; out[1] = 2 * 3.14159265358979323846264338327950288f; return 2; }
 	return -1;
 }
+
+/* PathAggregate (bih.h:29-66), whose bodies the reference has commented out, as those bodies read once their two
+ * slips are set right: set()'s loop counts `i--` from 0 (bih.h:48, it would stop after one counter) and the
+ * conversion shifts once more after the last counter (bih.h:60-63, which drops counter 0 and reverses the order).
+ * What the design needs is that an aggregate of one path converts back to that path: counter i belongs to bit i.
+ * One aggregate per PIXEL (the reference indexes them by thread slot, renderer.cu:380,386, so that after a
+ * re-sort a slot would keep voting with another pixel's history). */
+void orc_path_votes(const uint64_t *path_keys, int32_t *votes, uint32_t n, int reset)
+{
+	uint32_t px, i;
+	for (px = 0; px < n; px++) {
+		uint64_t bits = path_keys[px];
+		for (i = 0; i < 64; i++) {
+			const int32_t vote = (bits & 1u) ? -1 : 1;          /* bih.h:39,49 */
+			int32_t *w = &votes[(size_t)i * n + px];
+			*w = reset ? vote : *w + vote;
+			bits >>= 1;
+		}
+	}
+}
+
+void orc_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n)
+{
+	uint32_t px, i;
+	for (px = 0; px < n; px++) {
+		uint64_t path = 0;
+		for (i = 0; i < 64; i++)
+			if (votes[(size_t)i * n + px] < 0) path |= (uint64_t)1 << i; /* bih.h:61 */
+		keys[px] = path;
+	}
+}

@@ -178,6 +178,12 @@ void orc_refract(const float i[3], const float n[3], float eta, float out[3]);
 void orc_rotate(const float v[3], float angle, const float axis[3], float out[3]);
 /* Renderer::moveCamera (renderer.cu:145-166) */
 void orc_move_camera(orc_camera *cam, const float pos[2], const float dir[2]);
+/* PathAggregate (bih.h:29-66) for every pixel: 64 signed vote counters per pixel, votes[bit * n + pixel].
+ * reset != 0: PathAggregate::set (the frames == 0 branch, renderer.cu:386), counter = path bit ? -1 : +1;
+ * otherwise PathAggregate::add (renderer.cu:380), counter += path bit ? -1 : +1. */
+void orc_path_votes(const uint64_t *path_keys, int32_t *votes, uint32_t n, int reset);
+/* PathAggregate::operator uint64_t (bih.h:55-65): bit i of the key is set where counter i is negative */
+void orc_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n);
 /* known-answer dispatcher: evaluates one record of tests/golden/glm_kat.json */
 int orc_kat(const char *fn, const float *in, float *out);
 

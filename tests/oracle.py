@@ -81,6 +81,10 @@ def lib():
         L.orc_slab.argtypes = [c_float_p] * 4 + [C.c_float]
         L.orc_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, c_float_p]
         L.orc_move_camera.argtypes = [C.POINTER(OrcCamera), c_float_p, c_float_p]
+        L.orc_path_votes.restype = None
+        L.orc_path_votes.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_uint32, C.c_int]
+        L.orc_vote_keys.restype = None
+        L.orc_vote_keys.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_uint32]
         L.orc_kat.restype = C.c_int
         L.orc_kat.argtypes = [C.c_char_p, c_float_p, c_float_p]
         _lib = L
@@ -222,3 +226,21 @@ class OracleScene:
         self.L.orc_trace_rays(self.h, n, _fp(o), _fp(d), None if tm is None else _fp(tm), hit.ctypes.data_as(C.POINTER(C.c_uint8)),
                               _fp(t), prim.ctypes.data_as(c_u32_p), _fp(pos), _fp(nrm))
         return dict(hit=hit, t=t, prim=prim, position=pos, normal=nrm)
+
+
+class PathVotes:
+    """The reference's per-pixel PathAggregate table (bih.h:29-66) on the CPU: votes[bit][pixel]."""
+
+    def __init__(self, n):
+        self.n = n
+        self.votes = np.zeros((64, n), np.int32)
+
+    def vote(self, path_keys, reset):
+        k = np.ascontiguousarray(path_keys, np.uint64).reshape(-1)
+        assert len(k) == self.n
+        lib().orc_path_votes(k.ctypes.data_as(C.POINTER(C.c_uint64)), self.votes.ctypes.data_as(C.POINTER(C.c_int32)), self.n, 1 if reset else 0)
+
+    def keys(self):
+        out = np.zeros(self.n, np.uint64)
+        lib().orc_vote_keys(self.votes.ctypes.data_as(C.POINTER(C.c_int32)), out.ctypes.data_as(C.POINTER(C.c_uint64)), self.n)
+        return out

@@ -834,3 +834,43 @@ def test_flythrough_camera_full_size(core, built):
         assert 0.3 < (pid != 0xFFFFFFFF).mean() < 0.9
     finally:
         core.set_camera(b.scene.camera)
+
+
+def test_path_vote_table(core, built, orc):
+    """The per-pixel vote table of the reference's adaptive assignment (PathAggregate, bih.h:29-66) on the GPU against
+    the oracle's: real path keys of accumulating Cornell frames, set on the first frame, added on the others; the
+    counters and the majority keys are equal bit for bit, and so is the pixel table sorted by them."""
+    import torch
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 192, 108
+    n = w * h
+    core.resize(w, h)
+    keys = torch.zeros(n, dtype=torch.int64, device="cuda")
+    votes = torch.full((64, n), 12345, dtype=torch.int32, device="cuda")  # whatever was there: set() overwrites
+    major = torch.zeros(n, dtype=torch.int64, device="cuda")
+    table = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ref_votes = orc.PathVotes(n)
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for f in range(5):
+            core.render(w, h, seed=900 + f, frames=f, max_bounces=2, path_keys_dev=C.c_void_p(keys.data_ptr()))
+            core.vote_paths(C.c_void_p(keys.data_ptr()), C.c_void_p(votes.data_ptr()), n, reset=(f == 0))
+            ref = b.oracle.render(w, h, seed=900 + f, frames=f, max_bounces=2)
+            ref_votes.vote(ref["path_key"], reset=(f == 0))
+            core.sync()
+            assert np.array_equal(keys.cpu().numpy().view(np.uint64), ref["path_key"].reshape(-1))
+            assert np.array_equal(votes.cpu().numpy(), ref_votes.votes)
+        core.vote_keys(C.c_void_p(votes.data_ptr()), C.c_void_p(major.data_ptr()), n)
+        core.sort_pixel_map(C.c_void_p(major.data_ptr()), C.c_void_p(table.data_ptr()), n)
+        core.sync()
+    finally:
+        core.use_own_stream()
+    want = ref_votes.keys()
+    assert np.array_equal(major.cpu().numpy().view(np.uint64), want)
+    assert len(np.unique(want)) > 4   # the votes tell pixels apart
+    assert np.array_equal(table.cpu().numpy(), np.argsort(want, kind="stable").astype(np.int32))
+    # the context-owned table: allocated on request for the current size, zeroed
+    p = core._lib.acr_hip_path_votes(core._h)
+    assert p
+    assert core._lib.acr_hip_path_votes(core._h) == p   # the same table on every call

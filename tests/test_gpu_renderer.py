@@ -82,9 +82,10 @@ def test_renderer_errors(acr):
 
 
 def test_adaptive_assignment_in_the_render_loop(acr, orc, built):
-    """Renderer with the reference's adaptive assignment switched on: every 3 still frames the pixel table is
-    re-sorted by the keys of the frame just rendered (renderer.cu:457-461), a camera move resets it
-    (renderer.cu:165,344-348).  The accumulated image equals the oracle's run through the same tables."""
+    """Renderer with the reference's adaptive assignment switched on: every frame's path keys are voted into the
+    per-pixel aggregates (bih.h:29-66; renderer.cu:380,386), every 3 still frames the pixel table is re-sorted by the
+    aggregates' majority keys (renderer.cu:457-461), a camera move resets both (renderer.cu:165,344-348).  The
+    accumulated image equals the oracle's run through the same tables."""
     b = built["cornell-box-cycles"]
     w, h = 160, 96
     n = w * h
@@ -96,14 +97,16 @@ def test_adaptive_assignment_in_the_render_loop(acr, orc, built):
 
         def run(frames, camera=None):
             screen, table, tables = None, None, []
+            votes = orc.PathVotes(n)
             for f in range(frames):
                 r.render()
                 ref = b.oracle.render(w, h, seed=70 + f, frames=f, max_bounces=3, screen=screen, pixel_map=table, camera=camera)
                 screen = ref["screen"]
+                votes.vote(ref["path_key"], reset=(f == 0))
                 if f == 0:
                     table = None  # frames == 0 renders through the identity and resets the table
                 if (f + 1) % 3 == 0:
-                    table = np.argsort(ref["path_key"].reshape(-1), kind="stable").astype(np.int32)
+                    table = np.argsort(votes.keys(), kind="stable").astype(np.int32)
                     tables.append(table)
             img, _, _ = r.read()
             assert np.array_equal(img.view(np.uint32), screen.view(np.uint32))

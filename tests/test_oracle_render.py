@@ -124,3 +124,32 @@ def test_pixel_map_permutes_work_not_pixels(built):
     a = o.render(w, h, seed=4, frames=1, max_bounces=1, screen=base.copy())["screen"]
     b = o.render(w, h, seed=4, frames=1, max_bounces=1, screen=base.copy(), pixel_map=perm)["screen"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_path_aggregate_votes(orc):
+    """PathAggregate (bih.h:29-66) as designed: an aggregate set from one path converts back to that path; adding
+    paths makes every bit a majority vote, a tie (counter 0) reads as 0; set starts over."""
+    rng = np.random.default_rng(3)
+    n = 500
+    v = orc.PathVotes(n)
+    first = rng.integers(0, 2 ** 63, n, dtype=np.uint64) | (rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63))
+    v.vote(first, reset=True)
+    assert np.array_equal(v.keys(), first)
+    assert set(np.unique(v.votes)) <= {-1, 1}
+    frames = [first]
+    for _ in range(4):
+        k = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+        frames.append(k)
+        v.vote(k, reset=False)
+    ones = sum(((f[None, :] >> np.arange(64, dtype=np.uint64)[:, None]) & np.uint64(1)).astype(np.int64) for f in frames)
+    assert np.array_equal(v.votes, (5 - 2 * ones).astype(np.int32))
+    want = np.zeros(n, np.uint64)
+    for i in range(64):
+        want |= (ones[i] >= 3).astype(np.uint64) << np.uint64(i)
+    assert np.array_equal(v.keys(), want)
+    v.vote(frames[1], reset=False)  # six frames: three against three is no majority
+    ones6 = ones + ((frames[1][None, :] >> np.arange(64, dtype=np.uint64)[:, None]) & np.uint64(1)).astype(np.int64)
+    tie = (ones6 == 3)
+    assert tie.any() and not ((v.keys()[None, :] >> np.arange(64, dtype=np.uint64)[:, None]) & np.uint64(1)).astype(bool)[tie].any()
+    v.vote(frames[2], reset=True)
+    assert np.array_equal(v.keys(), frames[2])
