@@ -285,7 +285,10 @@ namespace
 		// Trees and triangles in HBM: those kernels are compiled for three waves per SIMD (no register spills), so
 		// three workgroups share a CU's 160 KiB.  A deep mesh tree keeps as many of its deepest levels' waiting-child
 		// entries in LDS as that allows (every level of a 22-level tree); the levels above go to global memory.
-		constexpr size_t kHbmBudget = size_t(52) * 1024;
+#ifndef ACR_HBM_LDS_KB
+#define ACR_HBM_LDS_KB 52
+#endif
+		constexpr size_t kHbmBudget = size_t(ACR_HBM_LDS_KB) * 1024;
 		uint32_t meshLdsLevels = h.max_mesh_depth;
 		if (splitDeepColumns) {
 			const size_t fixed = size_t(3) * colorLevels * kBlock * 4 + size_t(h.small_slots) * 16;
