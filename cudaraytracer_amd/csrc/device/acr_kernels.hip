@@ -79,6 +79,11 @@ static_assert(ACR_BLOCK_SLOTS % ACR_BLOCK == 0 && ACR_BLOCK % 64 == 0, "a block 
 #define ACR_WAVE_KERNEL_WAVES 4
 #endif
 
+// triangle records of an HBM-resident leaf fetched per memory round trip
+#ifndef ACR_TRIS_PER_TRIP
+#define ACR_TRIS_PER_TRIP 5
+#endif
+
 extern __shared__ uint4 g_lds[];
 
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
@@ -670,17 +675,24 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 			test(i, mem.large(ts), mem.large(ts + 1), mem.large(ts + 2));
 		}
 	} else {
-		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so three records are fetched per
-		// trip (the first one again where the leaf has no more) and tested in item order.  Four bring nothing more.
-		for (uint32_t i = start; i < end; i += 3) {
-			const uint32_t i1 = i + 1 < end ? i + 1 : i, i2 = i + 2 < end ? i + 2 : i;
-			const uint32_t ts = triBase + i * kTriSlots, ts1 = triBase + i1 * kTriSlots, ts2 = triBase + i2 * kTriSlots;
-			const uint4 a0 = mem.large(ts), a1 = mem.large(ts + 1), a2 = mem.large(ts + 2);
-			const uint4 b0 = mem.large(ts1), b1 = mem.large(ts1 + 1), b2 = mem.large(ts1 + 2);
-			const uint4 c0 = mem.large(ts2), c1 = mem.large(ts2 + 1), c2 = mem.large(ts2 + 2);
-			test(i, a0, a1, a2);
-			if (i1 != i) test(i1, b0, b1, b2);
-			if (i2 != i) test(i2, c0, c1, c2);
+		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so ACR_TRIS_PER_TRIP records are fetched
+		// per trip (the first one again where the leaf has no more) and tested in item order (10 M-triangle soup, 4.8 triangles
+		// per leaf on average: 3.06 ms with three per trip, 3.00 with four, 2.94 with five, 2.96 with six).
+		for (uint32_t i = start; i < end; i += ACR_TRIS_PER_TRIP) {
+			uint4 r[ACR_TRIS_PER_TRIP][3];
+			uint32_t it[ACR_TRIS_PER_TRIP];
+#pragma unroll
+			for (uint32_t k = 0; k < ACR_TRIS_PER_TRIP; k++) {
+				it[k] = i + k < end ? i + k : i;
+				const uint32_t ts = triBase + it[k] * kTriSlots;
+				r[k][0] = mem.large(ts);
+				r[k][1] = mem.large(ts + 1);
+				r[k][2] = mem.large(ts + 2);
+			}
+			test(i, r[0][0], r[0][1], r[0][2]);
+#pragma unroll
+			for (uint32_t k = 1; k < ACR_TRIS_PER_TRIP; k++)
+				if (it[k] != i) test(it[k], r[k][0], r[k][1], r[k][2]);
 		}
 	}
 }
