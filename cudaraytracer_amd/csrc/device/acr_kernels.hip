@@ -306,9 +306,13 @@ __device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &m
 {
 	const vec3 tmn = (mn - a.o) * a.invD;
 	const vec3 tmx = (mx - a.o) * a.invD;
+	// The near plane of an axis is the min-side one for a positive direction, the max-side one for a negative one
+	// (geometry.h:52-66).  With min <= max and nothing NaN, multiplying by invD keeps or reverses the order of the
+	// two distances accordingly, so near = the smaller of the two and far = the larger: same values, without the
+	// three sign tests and six selects.
 	Interval r;
-	r.tmin = fmax3(a.sx() ? tmx.x : tmn.x, a.sy() ? tmx.y : tmn.y, a.sz() ? tmx.z : tmn.z);
-	r.tmax = fmin3(a.sx() ? tmn.x : tmx.x, a.sy() ? tmn.y : tmx.y, a.sz() ? tmn.z : tmx.z);
+	r.tmin = fmax3(__builtin_fminf(tmn.x, tmx.x), __builtin_fminf(tmn.y, tmx.y), __builtin_fminf(tmn.z, tmx.z));
+	r.tmax = fmin3(__builtin_fmaxf(tmn.x, tmx.x), __builtin_fmaxf(tmn.y, tmx.y), __builtin_fmaxf(tmn.z, tmx.z));
 	return r;
 }
 __device__ __forceinline__ bool intervalHit(float tmin, float tmax, float tcur) { return tmin <= tmax && tmin < tcur && tmax > epsilon(); }
