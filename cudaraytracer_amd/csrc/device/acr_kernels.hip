@@ -1445,7 +1445,12 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 	col.meshGlobLevels = 0u;
 	col.meshGlobStride = 0u;
 	col.meshGlob = nullptr;
-	float *cstack = ldsF + p.lds_cstack_off + threadIdx.x;
+	// this lane's direct-term column; its address is formed where it is used (see slotNow below)
+	auto cstackNow = [&]() {
+		uint32_t t = threadIdx.x;
+		asm volatile("" : "+v"(t));
+		return ldsF + p.lds_cstack_off + t;
+	};
 	WaveLds wl;
 	{
 		float *base = ldsF + p.lds_wave_off + (threadIdx.x >> 6) * waveLdsWords(sc.num_objects);
@@ -1534,6 +1539,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 	// A path's pixel is written on the level it ends on: Color4(c_0,1) + (Color4(c_1,1) + (... + tail)), the
 	// recursion's association, then the running mean of renderer.cu:375-387.
 	auto writePixel = [&](vec4 contribution) {
+		float *cstack = cstackNow();
 		while (kept > 0) {
 			kept--;
 			const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
@@ -1564,7 +1570,16 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
 		if (alive && level > 0) counts += 1u << 20;
-		const bool hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
+		// The primary rays of a wave's 8 x 8 pixels, and the shadow rays of their hits, travel together: each lane walks
+		// for itself, as in renderSlot (its lanes reach the same objects at the same time anyway).  From the first bounce
+		// on the rays of a wave have nothing in common and the object tests are handed out across it.
+		const bool coherent = level == 0;
+		bool hit = false;
+		if (coherent) {
+			if (alive) hit = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f);
+		} else {
+			hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
+		}
 		bool ended = false;
 		vec4 tail(0, 0, 0, 1);
 		if (alive && (bail || !hit)) { // a miss: renderer.cu:315
@@ -1578,6 +1593,14 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		}
 		// direct illum (renderer.cu:247-248): Scene::lightPoint (scene.cu:273-292), the lights in step across the wave
 		vec3 lightSum(0, 0, 0);
+		if (coherent) {
+			if (alive) {
+				Counters lc = {0, 0, 0};
+				lightSum = lightPoint<true>(mem, sc, info.position, info.normal, state, lc, col, bail);
+				counts += lc.shadow;
+				if (bail) alive = false;
+			}
+		} else
 		for (uint32_t li = 0; li < sc.num_lights; li++) {
 			vec3 dir(0, 0, 1), c(0, 0, 0);
 			float t = 0.0f;
@@ -1691,6 +1714,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 				ended = true;
 			} else {
 				// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
+				float *cstack = cstackNow();
 				cstack[(3 * level + 0) * kBlock] = c.x;
 				cstack[(3 * level + 1) * kBlock] = c.y;
 				cstack[(3 * level + 2) * kBlock] = c.z;
