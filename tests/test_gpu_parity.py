@@ -874,3 +874,38 @@ def test_path_vote_table(core, built, orc):
     p = core._lib.acr_hip_path_votes(core._h)
     assert p
     assert core._lib.acr_hip_path_votes(core._h) == p   # the same table on every call
+
+
+def test_wave_tasks_with_more_candidates_than_the_list_holds(core, acr, orc):
+    """Thirty overlapping objects around the origin: nearly every ray enters nearly every object's box, so a wave has
+    many times the 128 tasks its list holds and serves its lanes group by group (down to a lane at a time).  Frames
+    equal the oracle's and the nested kernel's; translucent and mirror-like materials are among the objects."""
+    d = random_instanced_scene(acr, seed=11, n_objects=30)
+    for n in d.nodes:
+        if n["name"].startswith("Obj"):
+            m = np.array(n["transform"], np.float32).reshape(4, 4)
+            m[3, :3] *= 0.3           # pull every object towards its parent's origin: the boxes pile up
+            n["transform"] = [float(v) for v in m.reshape(-1)]
+    b = Built(acr, orc, d)
+    load(core, b)
+    w, h = 200, 120
+    ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=4)
+    img, pid, ht, st = render(core, w, h, seed=31, frames=0, max_bounces=4)
+    assert st.wave_tasks == 1 and st.scene_in_lds == 2
+    assert_same(img, pid, ht, st, ref)
+    assert (pid != 0xFFFFFFFF).mean() > 0.05 and st.rays_bounce > 1000
+    core.set_traversal(nested=True)
+    try:
+        img2, pid2, ht2, st2 = render(core, w, h, seed=31, frames=0, max_bounces=4)
+    finally:
+        core.set_traversal()
+    assert st2.wave_tasks == 0
+    assert_same(img2, pid2, ht2, st2, ref)
+    # accumulation through the wave kernel
+    core.resize(w, h)
+    screen = None
+    for f in range(3):
+        core.render(w, h, seed=40 + f, frames=f, max_bounces=3)
+        screen = b.oracle.render(w, h, seed=40 + f, frames=f, max_bounces=3, screen=screen)["screen"]
+    core.sync()
+    assert np.array_equal(core.read_framebuffer().view(np.uint32), screen.view(np.uint32))
