@@ -268,7 +268,7 @@ namespace
 		size_t stackBytes = layout(h.max_mesh_depth, columnFloats);
 		p.cstackOff = uint32_t(columnFloats);
 		// the whole scene in LDS: kernels compiled for four waves per SIMD, i.e. four workgroups per CU
-		const size_t waveBytes = size_t(kBlock / 64) * acr::dev::waveLdsWords(h.num_objects) * 4;
+		const size_t waveBytes = size_t(kBlock / 64) * acr::dev::waveLdsWords() * 4;
 		if (waveTasks && h.num_objects <= acr::dev::kWaveMaxObjects && size_t(h.total_slots) * 16 + stackBytes + waveBytes <= kLdsBudget) {
 			p.ldsMode = 2;
 			p.stackSlot = h.total_slots;

@@ -65,15 +65,14 @@ namespace dev
 	};
 
 	// Wave-cooperative kernel: a wave's task list holds kWaveCap object tests (ACR_WAVE_TASK_SLOTS per lane), and a
-	// wave owns waveLdsWords(num_objects) 4-byte words of LDS: the tasks' results (kWaveCap), the task list
-	// (kWaveCap 16-bit entries) and per object two ballot halves and a list offset.  Lane k of a wave collects
-	// what belongs to object k, hence at most 64 objects.
+	// wave owns waveLdsWords() 4-byte words of LDS: the tasks' results (kWaveCap) and the task list (kWaveCap 16-bit
+	// entries).  A lane keeps the objects whose boxes its ray enters as a 64-bit mask, hence at most 64 objects.
 #ifndef ACR_WAVE_TASK_SLOTS
 #define ACR_WAVE_TASK_SLOTS 2
 #endif
 	constexpr uint32_t kWaveCap = 64u * ACR_WAVE_TASK_SLOTS;
 	constexpr uint32_t kWaveMaxObjects = 64;
-	constexpr uint32_t waveLdsWords(uint32_t numObjects) { return kWaveCap + kWaveCap / 2u + 3u * numObjects; }
+	constexpr uint32_t waveLdsWords() { return kWaveCap + kWaveCap / 2u; }
 
 	// workgroups of the list pass
 	constexpr uint32_t kRedoGrid = 64;
