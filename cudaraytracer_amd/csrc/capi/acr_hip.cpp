@@ -540,7 +540,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	memcpy(h.scene_min, s->scene_min, 12);
 	memcpy(h.scene_max, s->scene_max, 12);
 
-	std::vector<uint4> blob(h.total_slots ? h.total_slots : 1, make_uint4(0, 0, 0, 0));
+	std::vector<uint4> blob(size_t(h.total_slots) + acr::dev::kBlobPadSlots, make_uint4(0, 0, 0, 0)); // see kBlobPadSlots
 	for (uint32_t i = 0; i < snodeCount; i++)
 		putNode(blob[h.off_snodes + i], s->snode_left, s->snode_right, s->snode_start, s->snode_end, s->snode_flags, i, snodeCount);
 	// margin of the conservative world boxes: three to four orders of magnitude above fp32 rounding at scene scale

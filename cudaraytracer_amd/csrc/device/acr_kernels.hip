@@ -107,6 +107,21 @@ struct SceneMem
 		if constexpr (LARGE_LDS) return g_lds[slot];
 		else return g[slot];
 	}
+	// N consecutive slots.  From global memory that is one address and N constant offsets (slot + k formed in 32 bits
+	// would need an address computation of its own for every k); the blob is followed by kBlobPadSlots slots, so a run
+	// that starts inside it may end behind it.
+	template <int N>
+	__device__ __forceinline__ void largeRun(uint32_t slot, uint4 (&out)[N]) const
+	{
+		if constexpr (LARGE_LDS) {
+#pragma unroll
+			for (int k = 0; k < N; k++) out[k] = g_lds[slot + k];
+		} else {
+			const uint4 *__restrict__ q = g + size_t(slot);
+#pragma unroll
+			for (int k = 0; k < N; k++) out[k] = q[k];
+		}
+	}
 };
 
 struct Ray { vec3 o, d; };
@@ -462,9 +477,10 @@ __device__ __forceinline__ bool popNear(const LevelColumn &stack, uint32_t &pend
 // great-grandchildren on top, measured slower: 3.25 against 3.03 ms on the 10 M-triangle soup; so did requesting, while a
 // leaf's triangles are on their way, the subtree the walk will most likely resume at: 3.13 ms).  nodeCount: records of this tree (requests beyond the last one are moved onto it; what
 // they return is never used).
-template <bool KEYS = false, class LoadNode, class Leaf, class TCur>
-__device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, uint32_t nodeCount, const SlabArgs &sa, Interval box, const LevelColumn &stack, Leaf leaf, TCur tcur,
-                                                PathRec *path = nullptr)
+// loadRun(i, out): the records i, i + 1, ... of the tree into out[].
+template <bool KEYS = false, class LoadNode, class LoadRun, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, Interval box, const LevelColumn &stack,
+                                                Leaf leaf, TCur tcur, PathRec *path = nullptr)
 {
 	uint32_t idx = 0, level = 0, pending = 0;
 	float tminB = box.tmin, tmaxB = box.tmax;
@@ -495,16 +511,23 @@ __device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, uint32_t node
 		level++;
 		return goLeft ? 0u : 1u;
 	};
-	const uint32_t last = nodeCount - 1;
-	auto at = [&](uint32_t i) { return loadNode(i < last ? i : last); };
+	// The two children are neighbours in memory and so are the four grandchildren: one address each.  A node on the
+	// last two levels has no grandchildren (or children): the run is moved to the end of the tree, and nothing of it is used.
+	const uint32_t lastPair = nodeCount >= 2u ? nodeCount - 2u : 0u, lastQuad = nodeCount >= 4u ? nodeCount - 4u : 0u;
 	for (;;) {
 		// after a pop (or at the start) nothing of this subtree is at hand: the node and the two levels below it in one go
 		uint4 n = loadNode(idx);
 		bool popped = false;
 		for (;;) {
-			const uint4 c0 = at(2 * idx + 1), c1 = at(2 * idx + 2);
-			const uint32_t g = 4 * idx + 3;
-			const uint4 g0 = at(g), g1 = at(g + 1), g2 = at(g + 2), g3 = at(g + 3);
+			// (single variables: an array that is indexed by the two decisions below ends up in scratch memory)
+			uint4 c0, c1, g0, g1, g2, g3;
+			{
+				uint4 c[2], g[4];
+				loadRun(min(2u * idx + 1u, lastPair), c);
+				loadRun(min(4u * idx + 3u, lastQuad), g);
+				c0 = c[0], c1 = c[1];
+				g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+			}
 			if ((n.w & kNodeLeafBit) != 0)
 				break;
 			const uint32_t k = nodeStep(n);
@@ -624,7 +647,8 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 				return false;
 			};
 			auto tslack = [&]() { return tmp.t * kNearPruneSlack; };
-			bihTraverseNear(loadNode, (1u << q2.y) - 1u, sa, root, lc, leafNear, tslack);
+			auto loadRun = [&](uint32_t i, auto &out) { mem.largeRun(nodeBase + i, out); };
+			bihTraverseNear(loadNode, loadRun, (1u << q2.y) - 1u, sa, root, lc, leafNear, tslack);
 			// order.second == FLT_MAX: nothing lost in this mesh, and the hit (if any) replaced no earlier mesh's
 			if (order.second < FLT_MAX && order.second <= order.leafTmin) bail = true;
 		} else {
@@ -682,21 +706,17 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so ACR_TRIS_PER_TRIP records are fetched
 		// per trip (the first one again where the leaf has no more) and tested in item order (10 M-triangle soup, 4.8 triangles
 		// per leaf on average: 3.06 ms with three per trip, 3.00 with four, 2.94 with five, 2.96 with six).
+		// A leaf's records follow one another in memory: one address for the trip, and past the leaf's end whatever
+		// follows (read, never tested).  Every record is requested before the first test starts.
+		static_assert(ACR_TRIS_PER_TRIP * kTriSlots <= kBlobPadSlots + kTriSlots, "a trip may read past the last triangle");
 		for (uint32_t i = start; i < end; i += ACR_TRIS_PER_TRIP) {
-			uint4 r[ACR_TRIS_PER_TRIP][3];
-			uint32_t it[ACR_TRIS_PER_TRIP];
-#pragma unroll
-			for (uint32_t k = 0; k < ACR_TRIS_PER_TRIP; k++) {
-				it[k] = i + k < end ? i + k : i;
-				const uint32_t ts = triBase + it[k] * kTriSlots;
-				r[k][0] = mem.large(ts);
-				r[k][1] = mem.large(ts + 1);
-				r[k][2] = mem.large(ts + 2);
-			}
-			test(i, r[0][0], r[0][1], r[0][2]);
+			uint4 r[ACR_TRIS_PER_TRIP * kTriSlots];
+			mem.largeRun(triBase + i * kTriSlots, r);
+			__builtin_amdgcn_sched_barrier(0);
+			test(i, r[0], r[1], r[2]);
 #pragma unroll
 			for (uint32_t k = 1; k < ACR_TRIS_PER_TRIP; k++)
-				if (it[k] != i) test(it[k], r[k][0], r[k][1], r[k][2]);
+				if (i + k < end) test(i + k, r[k * kTriSlots], r[k * kTriSlots + 1], r[k * kTriSlots + 2]);
 		}
 	}
 }

@@ -44,6 +44,9 @@ namespace dev
 	constexpr uint32_t kMeshSlots = 3;
 	constexpr uint32_t kTriSlots = 3;
 	constexpr uint32_t kNormalSlots = 3;
+	// slots allocated (zeroed) behind the blob's last one: kernels fetch short runs of consecutive slots from one
+	// address without checking where the table they belong to ends
+	constexpr uint32_t kBlobPadSlots = 16;
 	constexpr uint32_t kMaterialSlots = 3;
 	constexpr uint32_t kLightSlots = 4;
 
