@@ -344,13 +344,25 @@ struct LevelColumn
 	uint32_t globLevels, globStride;
 	__device__ __forceinline__ void store(uint32_t level, float2 v) const
 	{
-		if (level >= globLevels) lds[(level - globLevels) * kBlock] = v;
-		else glob[size_t(level) * globStride] = v;
+		if (level >= globLevels) {
+			lds[(level - globLevels) * kBlock] = v;
+		} else {
+			glob[size_t(level) * globStride] = v;
+			// keeps the two stores apart: merged into one store through a selected pointer they become a flat store,
+			// which waits on both the LDS and the vector memory counter
+			asm volatile("");
+		}
 	}
 	__device__ __forceinline__ float2 load(uint32_t level) const
 	{
-		if (level >= globLevels) return lds[(level - globLevels) * kBlock];
-		return glob[size_t(level) * globStride];
+		float2 v;
+		if (level >= globLevels) {
+			v = lds[(level - globLevels) * kBlock];
+		} else {
+			v = glob[size_t(level) * globStride];
+			asm volatile("" : "+v"(v.x), "+v"(v.y)); // two loads, not one flat load through a selected pointer (see store)
+		}
+		return v;
 	}
 };
 
