@@ -86,6 +86,31 @@ static_assert(ACR_BLOCK_SLOTS % ACR_BLOCK == 0 && ACR_BLOCK % 64 == 0, "a block 
 
 extern __shared__ uint4 g_lds[];
 
+// The launch parameters, read again from the kernel argument segment at the place of the call.  A field the kernel
+// reads at its start and needs only at its end otherwise sits in a scalar register through every loop; there are more
+// such fields than registers, and the compiler parks them in lanes of a vector register (a vector instruction per
+// move).  What is read through this reference is fetched by scalar loads right here instead.
+// This lane's number in its wave, computed where it is asked for (the same number kept from a kernel's start to its
+// end costs a register through every loop, or a spill).
+__device__ __forceinline__ uint32_t laneNow()
+{
+	uint32_t l;
+	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+	return l;
+}
+
+typedef const __attribute__((address_space(4))) RenderParams LateParams;
+__device__ __forceinline__ LateParams &lateParams()
+{
+	const uint64_t a = reinterpret_cast<uint64_t>(__builtin_amdgcn_kernarg_segment_ptr());
+	uint32_t lo = uint32_t(a), hi = uint32_t(a >> 32);
+	// through vector registers, so that this also works where the lanes of the wave have gone separate ways
+	asm volatile("" : "+v"(lo), "+v"(hi));
+	lo = __builtin_amdgcn_readfirstlane(lo);
+	hi = __builtin_amdgcn_readfirstlane(hi);
+	return *reinterpret_cast<LateParams *>(uint64_t(lo) | (uint64_t(hi) << 32));
+}
+
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
 // Scene memory view.  SMALL/LARGE say whether that part of the blob was
@@ -1130,8 +1155,9 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if (!hit)
 			break; // renderer.cu:315
 		if (level == 0) {
-			if (p.primid) p.primid[outSlot] = info.prim;
-			if (p.hit_t) p.hit_t[outSlot] = info.t;
+			LateParams &q = lateParams();
+			if (q.primid) q.primid[outSlot] = info.prim;
+			if (q.hit_t) q.hit_t[outSlot] = info.t;
 			cnt.primaryHits++;
 		}
 		// direct illum (renderer.cu:247-248); the material record is fetched after the shadow rays
@@ -1213,15 +1239,16 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		const vec4 cl(cstack[(3 * level + 0) * kBlock], cstack[(3 * level + 1) * kBlock], cstack[(3 * level + 2) * kBlock], 1.0f);
 		contribution = cl + contribution;
 	}
-	if constexpr (KEYS) p.path_keys[index] = pathRec.path; // keyed by pixel, so that keys and pixels stay together when sorted
+	LateParams &q = lateParams();
+	if constexpr (KEYS) q.path_keys[index] = pathRec.path; // keyed by pixel, so that keys and pixels stay together when sorted
 
 	// average (renderer.cu:375-387)
-	float4 *px = p.screen + outSlot;
-	if (p.frames > 0) {
+	float4 *px = q.screen + outSlot;
+	if (q.frames > 0) {
 		const float4 old = *px;
 		vec4 s(old.x, old.y, old.z, old.w);
-		s = s * (float(p.frames) / float(p.frames + 1));
-		s = s + (contribution / float(p.frames + 1));
+		s = s * (float(q.frames) / float(q.frames + 1));
+		s = s + (contribution / float(q.frames + 1));
 		*px = make_float4(s.x, s.y, s.z, s.w);
 	} else {
 		*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
@@ -1562,12 +1589,13 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
 			contribution = cl + contribution;
 		}
-		float4 *px = p.screen + slotNow();
-		if (p.frames > 0) {
+		LateParams &q = lateParams();
+		float4 *px = q.screen + slotNow();
+		if (q.frames > 0) {
 			const float4 old = *px;
 			vec4 s(old.x, old.y, old.z, old.w);
-			s = s * (float(p.frames) / float(p.frames + 1));
-			s = s + (contribution / float(p.frames + 1));
+			s = s * (float(q.frames) / float(q.frames + 1));
+			s = s + (contribution / float(q.frames + 1));
 			*px = make_float4(s.x, s.y, s.z, s.w);
 		} else {
 			*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
@@ -1604,8 +1632,9 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 			ended = !bail;
 		}
 		if (alive && level == 0) {
-			if (p.primid) p.primid[slotNow()] = info.prim;
-			if (p.hit_t) p.hit_t[slotNow()] = info.t;
+			LateParams &q = lateParams();
+			if (q.primid) q.primid[slotNow()] = info.prim;
+			if (q.hit_t) q.hit_t[slotNow()] = info.t;
 			counts |= 1u << 28;
 		}
 		// direct illum (renderer.cu:247-248): Scene::lightPoint (scene.cu:273-292), the lights in step across the wave
@@ -1753,14 +1782,24 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 }
 
 // Adds one wave's ray counts to the per-tile and per-launch counters.
-__device__ __forceinline__ void reportCounts(const RenderParams &p, const SlotResult &res, uint32_t vblock)
+// Position in the tile list of block `vblock` of a tiled launch (0 for a full-frame launch): what renderSlot computes
+// at its start, once more for the kernel's last lines instead of kept in a register until then.
+template <class Params>
+__device__ __forceinline__ uint32_t tileOfBlock(const Params &p, uint32_t vblock)
 {
-	const uint32_t lane = threadIdx.x & 63u;
+	if (p.num_tiles == 0)
+		return 0u;
+	return vblock / ((p.tile_w >> 4) * (p.tile_h >> 4));
+}
+
+template <class Params>
+__device__ __forceinline__ void reportCounts(const Params &p, const SlotResult &res, uint32_t vblock, uint32_t tileNo)
+{
+	const uint32_t lane = laneNow();
 	const bool counted = res.active && !res.bail;
 	if (p.num_tiles != 0 && p.tile_rays) {
 		// a wave lies inside one 16x16 block, hence inside one tile
 		const uint32_t rays = waveSum((counted ? 1u : 0u) + res.cnt.shadow + res.cnt.bounce);
-		const uint32_t tileNo = __builtin_amdgcn_readfirstlane(res.tileNo);
 		if (lane == 0 && rays) atomicAdd(&p.tile_rays[tileNo], rays);
 	}
 	if (p.counters) {
@@ -1796,17 +1835,20 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 	// first the launch does not end on a few long workgroups while the rest of the GPU is idle.
 	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
 	const SlotResult res = renderSlot<FAST, KEYS, ONE>(p, mem, vblock, vtid);
+	LateParams &q = lateParams();
 	if constexpr (FAST) {
 		if (res.bail) {
-			const uint32_t at = atomicAdd(p.redo_count, 1u);
-			p.redo_list[at] = vblock * kSlots + vtid;
+			const uint32_t at = atomicAdd(q.redo_count, 1u);
+			q.redo_list[at] = vblock * kSlots + vtid;
 		}
 	}
-	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
-		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
-	if (p.block_cost && (threadIdx.x & 63u) == 0)
-		atomicAdd(&p.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
-	reportCounts(p, res, vblock);
+	const bool firstLane = laneNow() == 0;
+	const uint32_t tileNo = tileOfBlock(q, vblock);
+	if (q.num_tiles != 0 && q.tile_cycles && firstLane)
+		atomicAdd(&q.tile_cycles[tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	if (q.block_cost && firstLane)
+		atomicAdd(&q.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	reportCounts(q, res, vblock, tileNo);
 }
 
 // renderKernel for scenes resident in LDS and frames with bounces: the waves trace their rays together
@@ -1829,15 +1871,18 @@ __global__ void __launch_bounds__(kBlock, ACR_WAVE_KERNEL_WAVES) renderWaveKerne
 #ifdef ACR_WAVE_DEBUG
 	if ((threadIdx.x & 63u) == 0) atomicAdd(&g_waveDebug[9], (unsigned long long)(__builtin_readcyclecounter() - dbgK0));
 #endif
+	LateParams &q = lateParams();
 	if (res.bail) {
-		const uint32_t at = atomicAdd(p.redo_count, 1u);
-		p.redo_list[at] = vblock * kSlots + vtid;
+		const uint32_t at = atomicAdd(q.redo_count, 1u);
+		q.redo_list[at] = vblock * kSlots + vtid;
 	}
-	if (tiled && p.tile_cycles && (threadIdx.x & 63u) == 0)
-		atomicAdd(&p.tile_cycles[res.tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
-	if (p.block_cost && (threadIdx.x & 63u) == 0)
-		atomicAdd(&p.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
-	reportCounts(p, res, vblock);
+	const bool firstLane = laneNow() == 0;
+	const uint32_t tileNo = tileOfBlock(q, vblock);
+	if (q.num_tiles != 0 && q.tile_cycles && firstLane)
+		atomicAdd(&q.tile_cycles[tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	if (q.block_cost && firstLane)
+		atomicAdd(&q.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	reportCounts(q, res, vblock, tileNo);
 }
 
 // Renders the pixel slots listed by a FAST launch with the six-plane traversal: a fixed small grid that
