@@ -107,6 +107,7 @@ HIP_SYMBOLS = {
     "acr_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "acr_hip_use_own_stream": (C.c_int, [C.c_void_p]),
     "acr_hip_sync": (C.c_int, [C.c_void_p]),
+    "acr_hip_selftest_reciprocal": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "acr_hip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "acr_hip_set_block_order": (C.c_int, [C.c_void_p, C.c_uint32]),
     "acr_hip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneSoA)]),

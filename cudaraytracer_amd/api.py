@@ -191,6 +191,12 @@ class HipCore:
     def sync(self):
         self._check(self._lib.acr_hip_sync(self._h), "acr_hip_sync")
 
+    def selftest_reciprocal(self):
+        """acr_hip_selftest_reciprocal: argument patterns (of all 2^32) for which the kernels' reciprocal differs from 1.0f / x."""
+        n = C.c_uint64(0)
+        self._check(self._lib.acr_hip_selftest_reciprocal(self._h, C.byref(n)), "acr_hip_selftest_reciprocal")
+        return int(n.value)
+
     def read_framebuffer(self):
         out = np.zeros((self._hh, self._w, 4), dtype=np.float32)
         self._check(self._lib.acr_hip_read_framebuffer(self._h, out.ctypes.data_as(_capi.c_float_p), out.size), "read_framebuffer")

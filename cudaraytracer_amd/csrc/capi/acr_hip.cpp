@@ -463,6 +463,23 @@ int acr_hip_sync(acr_hip_ctx *ctx)
 	return ACR_OK;
 }
 
+int acr_hip_selftest_reciprocal(acr_hip_ctx *ctx, uint64_t *mismatches)
+{
+	if (!ctx || !mismatches) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	unsigned long long *differ = nullptr;
+	ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&differ), sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(differ, 0, sizeof(unsigned long long), ctx->stream);
+	if (e == hipSuccess) e = acr_dev_launch_reciprocal_check(differ, ctx->stream);
+	unsigned long long count = 0;
+	if (e == hipSuccess) e = hipMemcpyAsync(&count, differ, sizeof(count), hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(differ);
+	ACR_HIP_TRY(ctx, e);
+	*mismatches = count;
+	return ACR_OK;
+}
+
 int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 {
 	if (!ctx || !s) return fail(ctx, ACR_ERR_INVALID, "null argument");
@@ -513,6 +530,19 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	for (uint32_t m = 0; m < s->num_meshes && intervalOk; m++) {
 		const uint32_t nb = s->mesh_node_begin[m];
 		intervalOk = planesInsideBoxes(s->mesh_min + 3 * size_t(m), s->mesh_max + 3 * size_t(m), s->mnode_left + nb, s->mnode_right + nb, s->mnode_flags + nb);
+	}
+
+	// ... and are its triangles small enough for the triangle test's reciprocal?  (|det| <= |e1| |rd| |e2| must stay
+	// below 2^126 for normalised directions, see myIntersectRayTriangleEdges<NEWTON>; finite edges, |e1| |e2| < 2^120)
+	for (uint32_t i = 0; i < s->num_triangles && intervalOk; i++) {
+		const float *a = s->tri_p0 + 3 * size_t(i), *b = s->tri_p1 + 3 * size_t(i), *c = s->tri_p2 + 3 * size_t(i);
+		double l1 = 0, l2 = 0;
+		for (int k = 0; k < 3; k++) {
+			const double e1 = double(b[k] - a[k]), e2 = double(c[k] - a[k]); // the edges as the blob holds them (fp32 differences)
+			l1 += e1 * e1;
+			l2 += e2 * e2;
+		}
+		if (!(l1 * l2 < 0x1p240)) intervalOk = false; // also catches NaN and infinite edges
 	}
 
 	// ---- pack ----

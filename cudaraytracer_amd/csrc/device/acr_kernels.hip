@@ -160,6 +160,18 @@ struct SlabArgs
 		o = r.o;
 		invD = 1.0f / r.d;
 	}
+	// The interval form's init: 1 / d without the division (acr::math::reciprocalNewton), and whether the ray
+	// qualifies for that form.  A component of 1 / d that comes out as a normal number is the quotient, bit for bit;
+	// one that does not (a zero, denormal, huge, infinite or NaN direction component) disqualifies the ray, as an
+	// infinite 1 / d always did: its pixel is rendered by the six-plane pass, which divides.
+	__device__ __forceinline__ bool initInterval(const Ray &r)
+	{
+		o = r.o;
+		invD = vec3(acr::math::reciprocalNewton(r.d.x), acr::math::reciprocalNewton(r.d.y), acr::math::reciprocalNewton(r.d.z));
+		const float inf = __builtin_inff();
+		return __builtin_isnormal(invD.x) && __builtin_isnormal(invD.y) && __builtin_isnormal(invD.z) && fabsf(o.x) < inf && fabsf(o.y) < inf &&
+		       fabsf(o.z) < inf;
+	}
 	// the sign array of geometry.h:84-86, compared when needed instead of kept in three more registers
 	__device__ __forceinline__ bool sx() const { return invD.x < 0; }
 	__device__ __forceinline__ bool sy() const { return invD.y < 0; }
@@ -335,12 +347,6 @@ struct Interval
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-__device__ __forceinline__ bool rayIsFinite(const SlabArgs &a)
-{
-	const float inf = __builtin_inff();
-	return fabsf(a.invD.x) < inf && fabsf(a.invD.y) < inf && fabsf(a.invD.z) < inf && fabsf(a.o.x) < inf && fabsf(a.o.y) < inf &&
-	       fabsf(a.o.z) < inf;
-}
 // [max(near), min(far)] of a box with min <= max, for a finite ray
 __device__ __forceinline__ Interval boxInterval(const SlabArgs &a, const vec3 &mn, const vec3 &mx)
 {
@@ -649,7 +655,7 @@ struct OrderCheck
 };
 
 // Face::intersect (geometry.h:123-146) for the items [start, end) of a leaf
-template <bool NEAR = false, class Mem>
+template <bool NEAR = false, bool NEWTON = false, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
                                               struct LocalHit &tmp, bool &intersected, OrderCheck *order = nullptr, float leafTmin = 0.0f);
 
@@ -666,7 +672,7 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 	const uint32_t triBase = sc.off_tris + q2.x * kTriSlots;
 	bool intersected = false;
 	auto leaf = [&](uint32_t start, uint32_t end) {
-		leafTriangles(mem, triBase, q2.x, start, end, lr, tmp, intersected);
+		leafTriangles<false, FAST>(mem, triBase, q2.x, start, end, lr, tmp, intersected);
 		return false;
 	};
 	auto loadNode = [&](uint32_t i) { return mem.large(nodeBase + i); };
@@ -680,7 +686,7 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 		if constexpr (NEAR) {
 			OrderCheck order = {FLT_MAX, 0.0f};
 			auto leafNear = [&](uint32_t start, uint32_t end, float leafTmin) {
-				leafTriangles<true>(mem, triBase, q2.x, start, end, lr, tmp, intersected, &order, leafTmin);
+				leafTriangles<true, true>(mem, triBase, q2.x, start, end, lr, tmp, intersected, &order, leafTmin);
 				return false;
 			};
 			auto tslack = [&]() { return tmp.t * kNearPruneSlack; };
@@ -705,7 +711,7 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 	return false;
 }
 
-template <bool NEAR, class Mem>
+template <bool NEAR, bool NEWTON, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
                                               LocalHit &tmp, bool &intersected, OrderCheck *order, float leafTmin)
 {
@@ -715,7 +721,7 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 		const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
 		vec3 b;
 		float t;
-		if (myIntersectRayTriangleEdges(lr.o, lr.d, a, e1, e2, b, t)) {
+		if (myIntersectRayTriangleEdges<NEWTON>(lr.o, lr.d, a, e1, e2, b, t)) {
 			bool take = t < tmp.t;
 			if constexpr (NEAR) {
 				// An exact tie goes to the hit the reference finds first: items are numbered in the reference's
@@ -811,12 +817,13 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		lr.d = translaten(invN, r.d);
 	}
 	SlabArgs sa;
-	sa.init(lr);
 	if constexpr (FAST) {
-		if (!rayIsFinite(sa)) {
+		if (!sa.initInterval(lr)) {
 			bail = true;
 			return false;
 		}
+	} else {
+		sa.init(lr);
 	}
 
 	bool intersected = false;
@@ -874,12 +881,13 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
                                                const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f)
 {
 	SlabArgs sa;
-	sa.init(r);
 	if constexpr (FAST) {
-		if (!rayIsFinite(sa)) {
+		if (!sa.initInterval(r)) {
 			bail = true;
 			return false;
 		}
+	} else {
+		sa.init(r);
 	}
 	const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
 	bool intersected = false;
@@ -1319,12 +1327,9 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 	sa.o = vec3(0, 0, 0);
 	sa.invD = vec3(1, 1, 1);
 	bool part = active;
-	if (active) {
-		sa.init(r);
-		if (!rayIsFinite(sa)) {
-			bail = true;
-			part = false;
-		}
+	if (active && !sa.initInterval(r)) {
+		bail = true;
+		part = false;
 	}
 #ifdef ACR_WAVE_DEBUG
 	uint64_t dbgT0 = __builtin_readcyclecounter();
@@ -2148,6 +2153,46 @@ extern "C" hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t
 {
 	hipLaunchKernelGGL(acr::dev::orderBlocksKernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
 	return hipGetLastError();
+}
+
+// The reciprocals the kernels take without dividing -- acr::math::reciprocal, SlabArgs::initInterval and the
+// determinant's in myIntersectRayTriangleEdges -- against the division they stand for, on 2^24 argument patterns per
+// launch (the patterns whose top byte is `hi`).  Counts the patterns for which a result that the kernels would use is
+// neither the division's bits nor, like it, a NaN; and those inside [2^-126, 2^126] that would be sent to the slow path.
+__global__ void __launch_bounds__(256) reciprocalCheckKernel(unsigned long long *differ, uint32_t hi)
+{
+	const uint32_t bits = (hi << 24) | (blockIdx.x << 8) | threadIdx.x;
+	const float x = __uint_as_float(bits);
+	const float want = 1.0f / x;
+	auto same = [](float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p != p && q != q); };
+	bool ok = same(want, acr::math::reciprocal(x));
+	// the three-component form, with the argument in each place next to two harmless ones
+	const bool inRange = fabsf(x) >= 0x1p-126f && fabsf(x) <= 0x1p126f;
+	acr::dev::Ray r;
+	r.o = vec3(0, 0, 0);
+	acr::dev::SlabArgs a;
+	r.d = vec3(x, 1.0f, -4.0f);
+	bool q = a.initInterval(r);
+	ok = ok && (!q || (same(want, a.invD.x) && same(a.invD.y, 1.0f) && same(a.invD.z, -0.25f))) && (q || !inRange);
+	r.d = vec3(0.5f, x, 8.0f);
+	q = a.initInterval(r);
+	ok = ok && (!q || (same(want, a.invD.y) && same(a.invD.x, 2.0f) && same(a.invD.z, 0.125f))) && (q || !inRange);
+	r.d = vec3(-2.0f, 0.25f, x);
+	q = a.initInterval(r);
+	ok = ok && (!q || (same(want, a.invD.z) && same(a.invD.x, -0.5f) && same(a.invD.y, 4.0f))) && (q || !inRange);
+	// the range a determinant can have in the interval-form kernels
+	if (fabsf(x) >= acr::math::epsilon() && fabsf(x) <= 0x1p126f) ok = ok && same(want, acr::math::reciprocalNewton(x));
+	if (!ok) atomicAdd(differ, 1ull);
+}
+
+extern "C" hipError_t acr_dev_launch_reciprocal_check(unsigned long long *differ, hipStream_t stream)
+{
+	for (uint32_t hi = 0; hi < 256; hi++) {
+		hipLaunchKernelGGL(reciprocalCheckKernel, dim3(1u << 16), dim3(256), 0, stream, differ, hi);
+		const hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
 }
 
 extern "C" hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream)

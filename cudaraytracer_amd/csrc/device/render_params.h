@@ -95,6 +95,7 @@ namespace dev
 extern "C" {
 hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_iota(int32_t *values, uint32_t n, hipStream_t stream);
+hipError_t acr_dev_launch_reciprocal_check(unsigned long long *differ, hipStream_t stream);
 hipError_t acr_dev_launch_vote_paths(const uint64_t *keys, int32_t *votes, uint32_t n, int reset, hipStream_t stream);
 hipError_t acr_dev_launch_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n, hipStream_t stream);
 // order[0..n) = the numbers 0..n-1, the ones with the largest cost[] first (256 cost classes)

@@ -205,6 +205,15 @@ int acr_hip_set_stream(acr_hip_ctx *ctx, void *hip_stream);
 int acr_hip_use_own_stream(acr_hip_ctx *ctx);
 int acr_hip_sync(acr_hip_ctx *ctx);            /* cudaDeviceSynchronize at renderer.cu:422 */
 
+/* Self-test with no counterpart in the reference.  The kernels replace the divisions 1.0f / x of the reference's
+ * arithmetic (1 / ray direction, geometry.h:80; 1 / determinant, math.h:143; inversesqrt, GLM func_exponential.inl:149-153)
+ * by the hardware's reciprocal approximation and one Newton step wherever 2^-126 <= |x| <= 2^126, which returns the
+ * correctly rounded quotient there.  This call checks that claim on the GPU the context is bound to, for every one
+ * of the 2^32 binary32 argument patterns, against the division itself: *mismatches is the number of patterns for which
+ * the two differ (neither equal bits nor both NaN); anything but 0 means this GPU is not one the kernels were
+ * verified for.  Takes a fraction of a second; synchronises the context's stream. */
+int acr_hip_selftest_reciprocal(acr_hip_ctx *ctx, uint64_t *mismatches);
+
 /* Launch order of the blocks of 16 x 16 pixel slots.  The GPU starts workgroups in grid order and a launch ends
  * with its last workgroups, so which blocks come last matters: if they are expensive ones, most of the GPU idles
  * while they finish.  With every > 0 (default 64) the context measures the time per block of a configuration

@@ -213,6 +213,35 @@ def test_translucent_material_path(core, acr, orc, scene_data):
     assert st.rays_bounce > 0
 
 
+def test_reciprocal_shortcut_is_the_division_for_every_argument(core):
+    """The kernels form 1 / direction, 1 / determinant and inversesqrt with the hardware reciprocal plus one Newton step
+    where |x| lies in [2^-126, 2^126], and with the division elsewhere.  All 2^32 argument patterns against 1.0f / x
+    on this GPU: no pattern may differ (this is what lets the frames stay bit-identical to the oracle, whose CPU
+    division is correctly rounded)."""
+    assert core.selftest_reciprocal() == 0
+
+
+def test_scene_with_a_gigantic_triangle_keeps_the_division(core, acr, orc):
+    """The interval-form kernels take the determinant's reciprocal without dividing, which is the quotient only up to
+    |det| = 2^126; a scene is given to them only if |e1| |e2| < 2^120 for every triangle.  One triangle with edges of
+    6e18 behind two hundred small ones: the frame must come from the six-plane kernels and equal the oracle's."""
+    from conftest import duplicate_triangle_scene
+    data = duplicate_triangle_scene(acr, 100, seed=11)
+    m = data.meshes[0]
+    big = np.array([[-3e18, -3e18, -2.0], [3e18, -3e18, -2.0], [0.0, 3e18, -2.0]], np.float32)
+    m["positions"] = np.concatenate([m["positions"], big])
+    m["normals"] = np.concatenate([m["normals"], np.tile(np.array([[0, 0, 1]], np.float32), (3, 1))])
+    n0 = len(m["positions"]) - 3
+    m["indices"] = np.concatenate([m["indices"], np.array([[n0, n0 + 1, n0 + 2]], np.uint32)])
+    b = Built(acr, orc, data)
+    load(core, b)
+    ref = b.oracle.render(128, 96, seed=5, frames=0, max_bounces=2)
+    img, pid, ht, st = render(core, 128, 96, seed=5, frames=0, max_bounces=2)
+    assert st.interval_traversal == 0
+    assert_same(img, pid, ht, st, ref)
+    assert (pid != 0xFFFFFFFF).mean() > 0.9  # the big triangle fills the background
+
+
 def test_empty_scene_and_no_lights(core, acr, orc, scene_data):
     import copy
     d = copy.deepcopy(scene_data["triangles"])

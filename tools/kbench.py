@@ -46,7 +46,10 @@ def main():
 
     from cudaraytracer_amd import _capi
     if args.lib:
-        _capi._hip = _capi._bind(C.CDLL(os.path.abspath(args.lib), mode=C.RTLD_GLOBAL), _capi.HIP_SYMBOLS)
+        lib = C.CDLL(os.path.abspath(args.lib), mode=C.RTLD_GLOBAL)
+        # an older build may lack entry points this benchmark does not call
+        have = {k: v for k, v in _capi.HIP_SYMBOLS.items() if hasattr(lib, k)}
+        _capi._hip = _capi._bind(lib, have)
     import cudaraytracer_amd as acr
 
     t0 = time.perf_counter()
