@@ -411,6 +411,9 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 		uint4 n = loadNode(idx);
 		bool alive = true;
 		while ((n.w & kNodeLeafBit) == 0) {
+			// both children are requested before this node's arithmetic: whichever the walk takes is at hand when
+			// the decision is made (an internal node has both; they are neighbours in memory)
+			const uint4 childL = loadNode(2 * idx + 1), childR = loadNode(2 * idx + 2);
 			const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
 			const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
 			const bool sg = ia < 0;
@@ -439,6 +442,7 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 				else tmaxB = nearSideMax;
 				idx = 2 * idx + (hitL ? 1 : 2);
 				level++;
+				n = hitL ? childL : childR;
 			} else {
 				// neither child: resume at the deepest level whose right child is still waiting
 				if (pending == 0) {
@@ -452,8 +456,8 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 				tmaxB = b.y;
 				idx = 2 * (((idx + 1) >> (level - l)) - 1) + 2; // right child of this path's node on level l
 				level = l + 1;
+				n = loadNode(idx);
 			}
-			n = loadNode(idx);
 		}
 		if (!alive)
 			return;
