@@ -791,9 +791,10 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // (math.h:188-192), so the caller measures them.
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
 // PREFILTER = false: the caller has made the world-box test already (saWorld and tLimit are not read).
+// winner: if given, receives the triangle and the material of the object's closest hit (LocalHit::tri, ::material).
 template <bool FULL, bool FAST, bool PREFILTER = true, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, const Columns &col, bool &bail, float tLimit)
+                                                WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
@@ -845,6 +846,7 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	}
 
 	if (intersected) {
+		if (winner) *winner = make_uint2(tmp.tri, tmp.material);
 		// info.point.position = r.o + r.d * t in local space (geometry.h:140), then to world (scene.cu:428)
 		const vec3 pl = lr.o + lr.d * tmp.t;
 		const mat4 M = loadMat4(mem, os + 9);
@@ -869,6 +871,49 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 		}
 	}
 	return intersected;
+}
+
+// What objectIntersect<true> returns for a ray whose closest hit inside object `obj` is known to be triangle `tri`
+// (an earlier objectIntersect<false> of the same ray said so): the same local ray, that one triangle's test, and
+// the hit's world position, normal, material and primitive id -- without the walk through the mesh trees.
+template <class Mem>
+__device__ __forceinline__ void objectHitDetails(const Mem &mem, const SceneHeader &sc, uint32_t obj, uint32_t tri, uint32_t material, const Ray &r,
+                                                 WorldHit &info)
+{
+	const uint32_t os = sc.off_objects + obj * kObjectSlots;
+	const uint32_t flags = mem.small(os).w;
+	Ray lr;
+	{
+		uint32_t meshBegin, meshCount;
+		const mat4 invM = loadMat4(mem, os + 2);
+		const mat3 invN = loadMat3(mem, os + 6, meshBegin, meshCount);
+		lr.o = (flags & kObjInvAffine) ? translateAffine(invM, r.o) : translate(invM, r.o);
+		lr.d = translaten(invN, r.d);
+	}
+	const uint32_t ts = sc.off_tris + tri * kTriSlots;
+	const uint4 t0 = mem.large(ts), t1 = mem.large(ts + 1), t2 = mem.large(ts + 2);
+	const vec3 a(asF(t0.x), asF(t0.y), asF(t0.z));
+	const vec3 e1(asF(t0.w), asF(t1.x), asF(t1.y));
+	const vec3 e2(asF(t1.z), asF(t1.w), asF(t2.x));
+	vec3 bary(0, 0, 0);
+	float tl = 0.0f;
+	(void)myIntersectRayTriangleEdges<true>(lr.o, lr.d, a, e1, e2, bary, tl); // it hit before: same operands, same result
+	const vec3 pl = lr.o + lr.d * tl;
+	const mat4 M = loadMat4(mem, os + 9);
+	const vec3 pw = (flags & kObjFwdAffine) ? translateAffine(M, pl) : translate(M, pl);
+	info.t = length(pw - r.o);
+	info.position = pw;
+	info.material = material;
+	const uint32_t ns = sc.off_normals + tri * kNormalSlots;
+	const uint4 n0 = mem.large(ns), n1 = mem.large(ns + 1), n2 = mem.large(ns + 2);
+	const vec3 na(asF(n0.x), asF(n0.y), asF(n0.z));
+	const vec3 nb(asF(n0.w), asF(n1.x), asF(n1.y));
+	const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
+	const vec3 nl = bary.x * na + bary.y * nb + bary.z * nc; // geometry.h:141
+	uint32_t u0, u1;
+	const mat3 N = loadMat3(mem, os + 13, u0, u1);
+	info.normal = translaten(N, nl); // scene.cu:429
+	info.prim = t2.y;
 }
 
 // Scene::intersect (scene.cu:204-207): BIH<Object> traversal in world space.
@@ -1297,13 +1342,14 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 __device__ unsigned long long g_waveDebug[16];
 #define g_dbgAcc wl.dbg
 #endif
-constexpr uint32_t kTaskHit = 0x8000u, kTaskBail = 0x4000u;
+// a task: lane (6 bits) | object (6) | kTaskBail | kTaskHit | triangle of the object's closest hit (kTaskTriBits) | its material
+constexpr uint32_t kTaskHit = 0x2000u, kTaskBail = 0x1000u, kTaskTriShift = 14u;
 
 // LDS of one wave for the steps above; offsets in 4-byte words from the wave's base
 struct WaveLds
 {
 	float *results;     // [kWaveCap] world distance of each task's hit (FLT_MAX: info would not be replaced)
-	uint16_t *queue;    // [kWaveCap] lane | object << 6, then | kTaskHit | kTaskBail
+	uint32_t *queue;    // [kWaveCap] lane | object << 6, then | kTaskHit | kTaskBail | (triangle | material << kTaskTriBits) << kTaskTriShift
 #ifdef ACR_WAVE_DEBUG
 	uint64_t *dbg;      // per-lane accumulators; lane 0's are added to g_waveDebug when the wave ends
 #endif
@@ -1388,7 +1434,7 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 		if (inGroup) {
 			uint32_t at = myBase;
 			for (uint64_t m = candMask; m != 0; m &= m - 1)
-				wl.queue[at++] = uint16_t(lane | (uint32_t(__builtin_ctzll(m)) << 6));
+				wl.queue[at++] = lane | (uint32_t(__builtin_ctzll(m)) << 6);
 		}
 #ifdef ACR_WAVE_DEBUG
 		{
@@ -1406,7 +1452,7 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 		for (uint32_t base = 0; base < queued; base += 64u) {
 			const uint32_t task = base + lane;
 			const bool valid = task < queued;
-			const uint32_t e = valid ? uint32_t(wl.queue[task]) : 0u;
+			const uint32_t e = valid ? wl.queue[task] : 0u;
 			const int rl = int(e & 63u);
 			Ray tr;
 			tr.o = vec3(__shfl(r.o.x, rl, 64), __shfl(r.o.y, rl, 64), __shfl(r.o.z, rl, 64));
@@ -1415,9 +1461,10 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 				WorldHit th;
 				th.t = FLT_MAX;
 				testBail = false;
-				const bool hit = objectIntersect<false, true, false>(mem, sc, e >> 6, tr, sa, th, col, testBail, FLT_MAX);
+				uint2 won = make_uint2(0u, 0u);
+				const bool hit = objectIntersect<false, true, false>(mem, sc, (e >> 6) & 63u, tr, sa, th, col, testBail, FLT_MAX, SHADOW ? nullptr : &won);
 				wl.results[task] = th.t;
-				wl.queue[task] = uint16_t(e | (hit ? kTaskHit : 0u) | (testBail ? kTaskBail : 0u));
+				wl.queue[task] = e | (hit ? kTaskHit : 0u) | (testBail ? kTaskBail : 0u) | ((won.x | (won.y << kTaskTriBits)) << kTaskTriShift);
 			}
 		}
 		waveSync();
@@ -1441,7 +1488,7 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 					intersected |= hit;
 					if (hit && t < info.t) { // scene.cu:432
 						info.t = t;
-						best = i;
+						best = e;
 					}
 					if constexpr (SHADOW) {
 						if (info.t + epsilon() < lightT) {
@@ -1469,16 +1516,9 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 	} else {
 		// the closest hit once more, this time for everything a shaded hit needs
 		if (part && !bail && intersected && info.t < FLT_MAX) {
-			WorldHit full;
-			full.t = FLT_MAX;
-			full.material = 0;
-			full.prim = 0xFFFFFFFFu;
-			full.position = vec3(0, 0, 0);
-			full.normal = vec3(0, 0, 0);
-			testBail = false;
-			objectIntersect<true, true, false>(mem, sc, best, r, sa, full, col, testBail, FLT_MAX);
-			bail = bail || testBail;
-			info = full;
+			// (step B has left the winning task's triangle and material in its list entry)
+			const uint32_t won = best >> kTaskTriShift;
+			objectHitDetails(mem, sc, (best >> 6) & 63u, won & ((1u << kTaskTriBits) - 1u), won >> kTaskTriBits, r, info);
 		}
 		ACR_DBG_PHASE(8)
 		bailOut = bailOut || bail;
@@ -1511,7 +1551,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 	{
 		float *base = ldsF + p.lds_wave_off + (threadIdx.x >> 6) * waveLdsWords();
 		wl.results = base;
-		wl.queue = reinterpret_cast<uint16_t *>(wl.results + kWaveCap);
+		wl.queue = reinterpret_cast<uint32_t *>(wl.results + kWaveCap);
 	}
 #ifdef ACR_WAVE_DEBUG
 	uint64_t dbgAcc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

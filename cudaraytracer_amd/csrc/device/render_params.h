@@ -65,14 +65,17 @@ namespace dev
 	};
 
 	// Wave-cooperative kernel: a wave's task list holds kWaveCap object tests (ACR_WAVE_TASK_SLOTS per lane), and a
-	// wave owns waveLdsWords() 4-byte words of LDS: the tasks' results (kWaveCap) and the task list (kWaveCap 16-bit
-	// entries).  A lane keeps the objects whose boxes its ray enters as a 64-bit mask, hence at most 64 objects.
+	// wave owns waveLdsWords() 4-byte words of LDS: the tasks' results (kWaveCap) and the task list (kWaveCap 32-bit
+	// entries).  A lane keeps the objects whose boxes its ray enters as a 64-bit mask, hence at most 64 objects; a
+	// list entry also names the triangle and the material of the task's hit in kTaskTriBits and the bits left (18 in all).
 #ifndef ACR_WAVE_TASK_SLOTS
 #define ACR_WAVE_TASK_SLOTS 2
 #endif
 	constexpr uint32_t kWaveCap = 64u * ACR_WAVE_TASK_SLOTS;
 	constexpr uint32_t kWaveMaxObjects = 64;
-	constexpr uint32_t waveLdsWords() { return kWaveCap + kWaveCap / 2u; }
+	constexpr uint32_t kTaskTriBits = 12;
+	constexpr uint32_t kWaveMaxTriangles = 1u << kTaskTriBits, kWaveMaxMaterials = 1u << (18u - kTaskTriBits);
+	constexpr uint32_t waveLdsWords() { return 2u * kWaveCap; }
 
 	// workgroups of the list pass
 	constexpr uint32_t kRedoGrid = 64;

@@ -905,6 +905,29 @@ def test_path_vote_table(core, built, orc):
     assert core._lib.acr_hip_path_votes(core._h) == p   # the same table on every call
 
 
+def test_scene_with_more_materials_than_a_task_entry_names(core, acr, orc):
+    """A task of the wave-cooperative kernel carries its hit's material in six bits: a scene with more than 64
+    materials is rendered by the kernel in which every lane makes its own object tests, with the same frames."""
+    from conftest import duplicate_triangle_scene
+    data = duplicate_triangle_scene(acr, 60, seed=3)
+    data.materials = [dict(diffuse=[0.1 + 0.01 * k, 0.8, 0.5], ambient=[0, 0, 0], specular=[0.3, 0.3, 0.3], refracti=0.0) for k in range(70)]
+    data.meshes[0]["material"] = 69
+    b = Built(acr, orc, data)
+    load(core, b)
+    ref = b.oracle.render(160, 96, seed=8, frames=0, max_bounces=3)
+    img, pid, ht, st = render(core, 160, 96, seed=8, frames=0, max_bounces=3)
+    assert st.wave_tasks == 0 and st.scene_in_lds == 2 and st.interval_traversal == 1
+    assert_same(img, pid, ht, st, ref)
+    data.materials = data.materials[:64]
+    data.meshes[0]["material"] = 63
+    b = Built(acr, orc, data)
+    load(core, b)
+    ref = b.oracle.render(160, 96, seed=8, frames=0, max_bounces=3)
+    img, pid, ht, st = render(core, 160, 96, seed=8, frames=0, max_bounces=3)
+    assert st.wave_tasks == 1
+    assert_same(img, pid, ht, st, ref)
+
+
 def test_wave_tasks_with_more_candidates_than_the_list_holds(core, acr, orc):
     """Thirty overlapping objects around the origin: nearly every ray enters nearly every object's box, so a wave has
     many times the 128 tasks its list holds and serves its lanes group by group (down to a lane at a time).  Frames
