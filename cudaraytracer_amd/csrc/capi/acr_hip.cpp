@@ -612,6 +612,9 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 			}
 		}
 		w[3] = flags;
+		// the object's first mesh (0 for an object without meshes: a valid record number when there are meshes at all,
+		// and its record is then read without being used)
+		w[7] = s->obj_mesh_count[i] ? s->obj_mesh_ids[s->obj_mesh_begin[i]] : 0u;
 		memcpy(w + 8, MI, 64);
 		memcpy(w + 24, s->obj_inv_normal_transform + 9 * size_t(i), 36);
 		w[33] = s->obj_mesh_begin[i];

@@ -664,13 +664,28 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
                                               struct LocalHit &tmp, bool &intersected, OrderCheck *order = nullptr, float leafTmin = 0.0f);
 
 // Mesh::intersect (geometry.cu:52-61) for a local-space ray
+// A mesh's record: box, material, where its nodes and triangles start, tree depth.
+struct MeshRecord
+{
+	uint4 q0, q1, q2;
+};
+template <class Mem>
+__device__ __forceinline__ MeshRecord loadMeshRecord(const Mem &mem, const SceneHeader &sc, uint32_t meshId)
+{
+	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
+	MeshRecord m;
+	m.q0 = mem.small(ms);
+	m.q1 = mem.small(ms + 1);
+	m.q2 = mem.small(ms + 2);
+	return m;
+}
+
 template <bool FAST, class Mem>
-__device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, uint32_t meshId, const Ray &lr,
+__device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader &sc, const MeshRecord &rec, const Ray &lr,
                                               const SlabArgs &sa, LocalHit &tmp, const Columns &col, bool &bail)
 {
 	constexpr bool NEAR = FAST && Mem::kNearFirst;
-	const uint32_t ms = sc.off_meshes + meshId * kMeshSlots;
-	const uint4 q0 = mem.small(ms), q1 = mem.small(ms + 1), q2 = mem.small(ms + 2);
+	const uint4 q0 = rec.q0, q1 = rec.q1, q2 = rec.q2;
 	const vec3 bmin(asF(q0.x), asF(q0.y), asF(q0.z)), bmax(asF(q1.x), asF(q1.y), asF(q1.z));
 	const uint32_t nodeBase = sc.off_mnodes + q1.w;
 	const uint32_t triBase = sc.off_tris + q2.x * kTriSlots;
@@ -812,6 +827,9 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 				return false;
 		}
 	}
+	// an object's first mesh is named in its box record: the list of mesh numbers (one more LDS round trip on the
+	// way to the mesh) is only read for further meshes
+	const uint32_t firstMesh = b1.w;
 	Ray lr;
 	uint32_t meshBegin, meshCount;
 	{
@@ -838,11 +856,14 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	tmp.material = 0;
 	tmp.bary = vec3(0, 0, 0);
 	for (uint32_t k = 0; k < meshCount; k++) {
-		const uint32_t idSlot = sc.off_objmesh + ((meshBegin + k) >> 2);
-		const uint4 ids = mem.small(idSlot);
-		const uint32_t sel = (meshBegin + k) & 3u;
-		const uint32_t meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
-		intersected |= meshIntersect<FAST>(mem, sc, meshId, lr, sa, tmp, col, bail);
+		uint32_t meshId = firstMesh;
+		if (k != 0) {
+			const uint32_t idSlot = sc.off_objmesh + ((meshBegin + k) >> 2);
+			const uint4 ids = mem.small(idSlot);
+			const uint32_t sel = (meshBegin + k) & 3u;
+			meshId = sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w));
+		}
+		intersected |= meshIntersect<FAST>(mem, sc, loadMeshRecord(mem, sc, meshId), lr, sa, tmp, col, bail);
 	}
 
 	if (intersected) {
