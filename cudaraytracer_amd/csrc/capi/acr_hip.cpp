@@ -87,6 +87,26 @@ struct acr_hip_ctx
 	} renderTiles, scatterTiles;
 	// interval traversal (see acr_kernels.hip): usable for this scene, forced off by the caller, and the
 	// buffers through which its launches hand pixels to the six-plane list pass
+	// Primary rays parallel to a coordinate plane (a direction component of exactly zero, 1 / d infinite): the interval
+	// form serves them too when no plane or box bound they can meet on that axis equals the camera's coordinate there
+	// (then no 0 * infinity, hence no NaN, can arise, and infinite slab distances compare like the reference's).
+	// Kept per axis for the tree over objects and per object (in its local space) for its mesh trees; scenes with
+	// more than kParallelMaxObjects objects or kParallelMaxValues such values go without.
+	struct AxisValues
+	{
+		std::vector<float> v[3];
+	};
+	struct LocalSpace
+	{
+		float invM[16];
+		bool affine;
+		AxisValues bounds;
+	};
+	AxisValues worldBounds;
+	std::vector<LocalSpace> localSpaces;
+	bool parallelOk = false;       // the tables above are filled
+	bool parallelBitsValid = false; // parallelBits belong to the current camera and scene
+	uint32_t parallelBits[acr::dev::kParallelWords] = {};
 	bool intervalOk = false;
 	bool leafOrderOk = false; // near-side-first walks of mesh trees can break exact ties by item position
 	int traversalMode = ACR_TRAVERSAL_AUTO;
@@ -129,6 +149,7 @@ namespace
 	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
 	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
 	constexpr size_t kLdsBudget = 64 * 1024;
+	constexpr size_t kParallelMaxValues = 1u << 16; // tree nodes of a scene whose plane values are kept for acr_hip_ctx::worldBounds
 
 	int fail(acr_hip_ctx *ctx, int code, const char *fmt, ...)
 	{
@@ -666,6 +687,53 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 		n[2] = make_uint4(fbits(n2[2]), 0, 0, 0);
 	}
 
+	// what a primary ray parallel to a coordinate plane must not start on (see acr_hip_ctx::worldBounds)
+	ctx->parallelOk = false;
+	ctx->parallelBitsValid = false;
+	ctx->worldBounds = acr_hip_ctx::AxisValues();
+	ctx->localSpaces.clear();
+	if (intervalOk && s->num_objects <= acr::dev::kParallelMaxObjects && size_t(snodeCount) + packedMeshNodes <= kParallelMaxValues) {
+		auto planes = [](acr_hip_ctx::AxisValues &out, const float *left, const float *right, const uint8_t *flags, uint32_t count) {
+			for (uint32_t i = 0; i < count; i++) {
+				if (flags[i] & ACR_NODE_LEAF) continue;
+				const int a = flags[i] & ACR_NODE_AXIS_MASK;
+				if (a > 2) continue;
+				out.v[a].push_back(left[i]);
+				out.v[a].push_back(right[i]);
+			}
+		};
+		for (int k = 0; k < 3; k++) {
+			ctx->worldBounds.v[k].push_back(s->scene_min[k]);
+			ctx->worldBounds.v[k].push_back(s->scene_max[k]);
+		}
+		planes(ctx->worldBounds, s->snode_left, s->snode_right, s->snode_flags, snodeCount);
+		ctx->localSpaces.resize(s->num_objects);
+		for (uint32_t i = 0; i < s->num_objects; i++) {
+			const uint32_t *w = reinterpret_cast<const uint32_t *>(&blob[h.off_objects + i * acr::dev::kObjectSlots]);
+			if (w[3] & acr::dev::kObjPrefilter)
+				for (int k = 0; k < 3; k++) {
+					float lo, hi;
+					memcpy(&lo, w + k, 4);
+					memcpy(&hi, w + 4 + k, 4);
+					ctx->worldBounds.v[k].push_back(lo);
+					ctx->worldBounds.v[k].push_back(hi);
+				}
+			acr_hip_ctx::LocalSpace &ls = ctx->localSpaces[i];
+			memcpy(ls.invM, w + 8, 64);
+			ls.affine = (w[3] & acr::dev::kObjInvAffine) != 0;
+			for (uint32_t k = 0; k < s->obj_mesh_count[i]; k++) {
+				const uint32_t m = s->obj_mesh_ids[s->obj_mesh_begin[i] + k];
+				for (int a = 0; a < 3; a++) {
+					ls.bounds.v[a].push_back(s->mesh_min[3 * size_t(m) + a]);
+					ls.bounds.v[a].push_back(s->mesh_max[3 * size_t(m) + a]);
+				}
+				const uint32_t nb = s->mesh_node_begin[m];
+				planes(ls.bounds, s->mnode_left + nb, s->mnode_right + nb, s->mnode_flags + nb, (1u << meshLevels[m]) - 1);
+			}
+		}
+		ctx->parallelOk = true;
+	}
+
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->blob) {
@@ -691,6 +759,7 @@ int acr_hip_set_camera(acr_hip_ctx *ctx, const acr_camera *camera)
 	if (!ctx->haveCamera || memcmp(&ctx->camera, camera, sizeof(*camera)) != 0) ctx->blockOrderInterval = 4;
 	ctx->camera = *camera;
 	ctx->haveCamera = true;
+	ctx->parallelBitsValid = false;
 	return ACR_OK;
 }
 
@@ -793,6 +862,30 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		p.inv_width = 1.0f / int(f->width);
 		p.inv_height = 1.0f / int(f->height);
 	}
+	if (ctx->parallelOk && !ctx->parallelBitsValid) {
+		using namespace acr::math;
+		auto clear = [](const acr_hip_ctx::AxisValues &b, const vec3 &o) {
+			uint32_t bits = 0;
+			for (int a = 0; a < 3; a++) {
+				bool hit = false;
+				for (float v : b.v[a]) hit = hit || v == o[a];
+				if (!hit) bits |= 1u << a;
+			}
+			return bits;
+		};
+		const vec3 cam(ctx->camera.position[0], ctx->camera.position[1], ctx->camera.position[2]);
+		memset(ctx->parallelBits, 0, sizeof(ctx->parallelBits));
+		ctx->parallelBits[acr::dev::kParallelWords - 1] = clear(ctx->worldBounds, cam);
+		for (size_t i = 0; i < ctx->localSpaces.size(); i++) {
+			const acr_hip_ctx::LocalSpace &ls = ctx->localSpaces[i];
+			mat4 m;
+			for (int j = 0; j < 4; j++) m.c[j] = vec4(ls.invM[4 * j], ls.invM[4 * j + 1], ls.invM[4 * j + 2], ls.invM[4 * j + 3]);
+			const vec3 lo = ls.affine ? translateAffine(m, cam) : translate(m, cam); // as objectIntersect forms it
+			ctx->parallelBits[i >> 3] |= clear(ls.bounds, lo) << (4 * (i & 7));
+		}
+		ctx->parallelBitsValid = true;
+	}
+	if (ctx->parallelOk) memcpy(p.parallel_ok, ctx->parallelBits, sizeof(p.parallel_ok));
 	p.width = f->width;
 	p.height = f->height;
 	p.blocks_x = (f->width + 15) / 16;

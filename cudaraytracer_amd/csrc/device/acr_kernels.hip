@@ -111,6 +111,14 @@ __device__ __forceinline__ LateParams &lateParams()
 	return *reinterpret_cast<LateParams *>(uint64_t(lo) | (uint64_t(hi) << 32));
 }
 
+// The rare way into the interval form for a PRIMARY ray that SlabArgs::initInterval turned away: 1 / d by division,
+// and every component either finite or infinite on an axis where the launch vouches that no bound the ray can meet
+// equals its origin's coordinate (RenderParams::parallel_ok; `space`: an object number, or kParallelMaxObjects for
+// the tree over objects).  Then no 0 * infinity arises, the infinite slab distances compare as the reference's do, and
+// the interval form's decisions are the six-plane form's.  Defined after SlabArgs.
+struct SlabArgs;
+__device__ __forceinline__ bool parallelRayQualifies(SlabArgs &sa, const struct Ray &r, uint32_t space);
+
 __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 
 // Scene memory view.  SMALL/LARGE say whether that part of the blob was
@@ -180,6 +188,23 @@ struct SlabArgs
 	// (bound - o) * invD on one axis: the per-plane term of geometry.h:52-66
 	__device__ __forceinline__ float plane(uint32_t axis, float bound) const { return (bound - o[int(axis)]) * invD[int(axis)]; }
 };
+
+__device__ __forceinline__ bool parallelRayQualifies(SlabArgs &sa, const Ray &r, uint32_t space)
+{
+	sa.init(r);
+	LateParams &q = lateParams();
+	uint32_t ok = 0;
+	if (space < kParallelMaxObjects) ok = (q.parallel_ok[space >> 3] >> (4u * (space & 7u))) & 7u;
+	else if (space == kParallelMaxObjects) ok = q.parallel_ok[kParallelWords - 1] & 7u;
+	const float inf = __builtin_inff();
+	bool good = fabsf(sa.o.x) < inf && fabsf(sa.o.y) < inf && fabsf(sa.o.z) < inf;
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+		const float v = fabsf(sa.invD[a]);
+		good = good && (v < inf || (v == inf && ((ok >> a) & 1u) != 0));
+	}
+	return good;
+}
 
 // Slab distances of a box, near plane / far plane per axis:
 // near.x = (bounds[sign.x].x - o.x) * invD.x, far.x = (bounds[1-sign.x].x - o.x) * invD.x
@@ -809,7 +834,7 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // winner: if given, receives the triangle and the material of the object's closest hit (LocalHit::tri, ::material).
 template <bool FULL, bool FAST, bool PREFILTER = true, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr)
+                                                WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr, bool primary = false)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
@@ -842,8 +867,10 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	SlabArgs sa;
 	if constexpr (FAST) {
 		if (!sa.initInterval(lr)) {
-			bail = true;
-			return false;
+			if (!(primary && parallelRayQualifies(sa, lr, obj))) {
+				bail = true;
+				return false;
+			}
 		}
 	} else {
 		sa.init(lr);
@@ -948,13 +975,15 @@ __device__ __forceinline__ void objectHitDetails(const Mem &mem, const SceneHead
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
 template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f)
+                                               const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f, bool primary = false)
 {
 	SlabArgs sa;
 	if constexpr (FAST) {
 		if (!sa.initInterval(r)) {
-			bail = true;
-			return false;
+			if (!(primary && parallelRayQualifies(sa, r, kParallelMaxObjects))) {
+				bail = true;
+				return false;
+			}
 		}
 	} else {
 		sa.init(r);
@@ -965,7 +994,8 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
 	auto leaf = [&](uint32_t start, uint32_t end) {
 		for (uint32_t i = start; i < end; i++) {
-			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (distPerT != 0.0f && (SHADOW || intersected)) ? info.t * distPerT : FLT_MAX);
+			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (distPerT != 0.0f && (SHADOW || intersected)) ? info.t * distPerT : FLT_MAX,
+			                                              nullptr, primary);
 			if constexpr (FAST) {
 				if (bail) return true;
 			}
@@ -1223,11 +1253,11 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if constexpr (KEYS) {
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
-			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f);
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f, true);
 			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail);
 		} else {
 			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d));
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d), level == 0);
 		}
 		if (FAST && bail) break;
 		if (!hit)
@@ -1691,7 +1721,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		const bool coherent = level == 0;
 		bool hit = false;
 		if (coherent) {
-			if (alive) hit = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f);
+			if (alive) hit = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f, true);
 		} else {
 			hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
 		}

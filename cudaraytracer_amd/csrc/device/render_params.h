@@ -20,6 +20,8 @@ namespace acr
 {
 namespace dev
 {
+	constexpr uint32_t kParallelMaxObjects = 64, kParallelWords = kParallelMaxObjects / 8 + 1;
+
 	struct RenderParams
 	{
 		SceneHeader scene;
@@ -46,6 +48,11 @@ namespace dev
 		unsigned long long *counters; // device [kCounterSlots][4] or null: pixels, shadow rays, bounce rays, primary hits
 		uint32_t *tile_rays;          // device [num_tiles] or null
 		uint32_t *tile_cycles;        // device [num_tiles] or null
+		// Which infinite components of 1 / d a PRIMARY ray may keep in the interval form: four bits per object (bit a:
+		// the camera's coordinate on axis a, in the object's local space, equals no mesh box bound or tree plane of
+		// the object on that axis), eight objects per word, and in the last word the same for the tree over objects
+		// and the objects' world boxes.  All zero: such rays go to the six-plane pass.
+		uint32_t parallel_ok[kParallelWords];
 		uint32_t lds_stack_slot;    // first LDS slot after the staged scene
 		uint32_t lds_cstack_off;    // floats from there to the per-bounce-level direct-term columns
 		uint32_t lds_wave_off;      // floats from there to the per-wave task tables of the wave-cooperative kernel

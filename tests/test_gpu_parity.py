@@ -221,6 +221,32 @@ def test_reciprocal_shortcut_is_the_division_for_every_argument(core):
     assert core.selftest_reciprocal() == 0
 
 
+def test_primary_rays_parallel_to_a_coordinate_plane(core, built, acr, orc):
+    """A primary ray through the middle column or row of an axis-aligned view has a direction component of exactly
+    zero, hence an infinite 1 / d.  The interval form serves it when the launch can vouch that none of the bounds it
+    meets on that axis equals the camera's coordinate there (Cornell: it can); otherwise, and always under
+    six_plane_only, the pixel goes to the six-plane pass.  Frames equal the oracle's either way."""
+    b = built["cornell-box-cycles"]
+    load(core, b)
+    w, h = 1920, 1080
+    served = 0
+    for seed in range(100, 130):
+        img, pid, ht, st = render(core, w, h, seed=seed, frames=0, max_bounces=1)
+        if seed in (100, 109, 117, 121, 122, 125, 126, 129):
+            assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=seed, frames=0, max_bounces=1))
+        served += st.six_plane_pixels == 0
+    # Without this, 7 of these 30 frames list a pixel (seeds 109, 117, 121, 122, 125, 126, 129).  The camera stands in the
+    # middle of the box, x = -2.78, where several mesh trees have a plane: rays of the middle column (d.x == 0) stay
+    # with the six-plane pass, those of the middle row (d.z == 0) are served.
+    assert served >= 26
+    # a camera that sits exactly on a plane of the tree over objects: nothing is vouched for on that axis
+    tri = built["triangles"]
+    load(core, tri)
+    for seed in range(20):
+        img, pid, ht, st = render(core, 640, 480, seed=seed, frames=0, max_bounces=1)
+        assert_same(img, pid, ht, st, tri.oracle.render(640, 480, seed=seed, frames=0, max_bounces=1))
+
+
 def test_scene_with_a_gigantic_triangle_keeps_the_division(core, acr, orc):
     """The interval-form kernels take the determinant's reciprocal without dividing, which is the quotient only up to
     |det| = 2^126; a scene is given to them only if |e1| |e2| < 2^120 for every triangle.  One triangle with edges of
