@@ -832,9 +832,11 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 // FAST: interval traversal; sets `bail` and returns when the local ray does not qualify for it.
 // PREFILTER = false: the caller has made the world-box test already (saWorld and tLimit are not read).
 // winner: if given, receives the triangle and the material of the object's closest hit (LocalHit::tri, ::material).
-template <bool FULL, bool FAST, bool PREFILTER = true, class Mem>
+// PARALLEL: the instantiation a primary ray is traced with again after the interval form turned it away for an
+// infinite 1 / d (parallelRayQualifies); kept apart from the common one so that the common one carries nothing for it.
+template <bool FULL, bool FAST, bool PREFILTER = true, bool PARALLEL = false, class Mem>
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
-                                                WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr, bool primary = false)
+                                                WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr)
 {
 	const uint32_t os = sc.off_objects + obj * kObjectSlots;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
@@ -866,11 +868,9 @@ __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeade
 	}
 	SlabArgs sa;
 	if constexpr (FAST) {
-		if (!sa.initInterval(lr)) {
-			if (!(primary && parallelRayQualifies(sa, lr, obj))) {
-				bail = true;
-				return false;
-			}
+		if (!(PARALLEL ? parallelRayQualifies(sa, lr, obj) : sa.initInterval(lr))) {
+			bail = true;
+			return false;
 		}
 	} else {
 		sa.init(lr);
@@ -973,17 +973,15 @@ __device__ __forceinline__ void objectHitDetails(const Mem &mem, const SceneHead
 // objects can be skipped without changing it.  (The boolean `intersected` the
 // reference also tests is implied: info.t can only drop below t through a
 // hit.)  Returns that occlusion flag for SHADOW, `intersected` otherwise.
-template <bool SHADOW, bool FAST, bool KEYS = false, class Mem>
+template <bool SHADOW, bool FAST, bool KEYS = false, bool PARALLEL = false, class Mem>
 __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader &sc, const Ray &r, WorldHit &info, float lightT,
-                                               const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f, bool primary = false)
+                                               const Columns &col, bool &bail, PathRec *path = nullptr, float distPerT = 0.0f)
 {
 	SlabArgs sa;
 	if constexpr (FAST) {
-		if (!sa.initInterval(r)) {
-			if (!(primary && parallelRayQualifies(sa, r, kParallelMaxObjects))) {
-				bail = true;
-				return false;
-			}
+		if (!(PARALLEL ? parallelRayQualifies(sa, r, kParallelMaxObjects) : sa.initInterval(r))) {
+			bail = true;
+			return false;
 		}
 	} else {
 		sa.init(r);
@@ -994,8 +992,8 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 	auto loadNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
 	auto leaf = [&](uint32_t start, uint32_t end) {
 		for (uint32_t i = start; i < end; i++) {
-			intersected |= objectIntersect<!SHADOW, FAST>(mem, sc, i, r, sa, info, col, bail, (distPerT != 0.0f && (SHADOW || intersected)) ? info.t * distPerT : FLT_MAX,
-			                                              nullptr, primary);
+			intersected |= objectIntersect<!SHADOW, FAST, true, PARALLEL>(mem, sc, i, r, sa, info, col, bail,
+			                                                              (distPerT != 0.0f && (SHADOW || intersected)) ? info.t * distPerT : FLT_MAX);
 			if constexpr (FAST) {
 				if (bail) return true;
 			}
@@ -1253,11 +1251,20 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		if constexpr (KEYS) {
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
-			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f, true);
+			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f);
 			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail);
 		} else {
 			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d), level == 0);
+			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d));
+			if constexpr (FAST) {
+				if (bail && level == 0) {
+					// a primary ray with an infinite 1 / d, most likely: once more, through the instantiation that admits it
+					// where the launch vouches for the axis (nothing has been written or counted yet)
+					bail = false;
+					info.t = FLT_MAX;
+					hit = sceneIntersect<false, true, false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f);
+				}
+			}
 		}
 		if (FAST && bail) break;
 		if (!hit)
@@ -1721,7 +1728,14 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		const bool coherent = level == 0;
 		bool hit = false;
 		if (coherent) {
-			if (alive) hit = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f, true);
+			if (alive) {
+				hit = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f);
+				if (bail) { // see renderSlot
+					bail = false;
+					info.t = FLT_MAX;
+					hit = sceneIntersect<false, true, false, true>(mem, sc, r, info, 0.0f, col, bail, nullptr, 1.0f);
+				}
+			}
 		} else {
 			hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
 		}
