@@ -148,6 +148,10 @@ namespace
 	constexpr uint32_t kBlockRows = kSlots / 16;
 	constexpr uint32_t kCounterSlots = acr::dev::kCounterSlots;
 	// LDS budget per workgroup for staging: leaves room for 2+ workgroups per CU (160 KiB)
+#ifndef ACR_ORDER_INTERVAL_AFTER_MOVE
+#define ACR_ORDER_INTERVAL_AFTER_MOVE 4
+#endif
+	constexpr uint32_t kOrderIntervalAfterMove = ACR_ORDER_INTERVAL_AFTER_MOVE;
 	constexpr size_t kLdsBudget = 64 * 1024;
 	constexpr size_t kParallelMaxValues = 1u << 16; // tree nodes of a scene whose plane values are kept for acr_hip_ctx::worldBounds
 
@@ -756,7 +760,7 @@ int acr_hip_set_camera(acr_hip_ctx *ctx, const acr_camera *camera)
 {
 	if (!ctx || !camera) return fail(ctx, ACR_ERR_INVALID, "null argument");
 	// a moved camera keeps the block order (neighbouring views cost alike) but has it re-measured soon
-	if (!ctx->haveCamera || memcmp(&ctx->camera, camera, sizeof(*camera)) != 0) ctx->blockOrderInterval = 4;
+	if (!ctx->haveCamera || memcmp(&ctx->camera, camera, sizeof(*camera)) != 0) ctx->blockOrderInterval = kOrderIntervalAfterMove;
 	ctx->camera = *camera;
 	ctx->haveCamera = true;
 	ctx->parallelBitsValid = false;
