@@ -2101,32 +2101,72 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 
 // Launch order of a frame's blocks from their measured cost, most expensive first: one workgroup, a counting
 // sort into 256 cost classes (linear in cost / largest cost).  The order inside a class is whatever the atomics
-// make it; frames do not depend on the order at all.
-__global__ void __launch_bounds__(1024) orderBlocksKernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order)
+// make it; frames do not depend on the order at all.  Every wave counts into bins of its own: one LDS atomic per
+// element, contended only inside the wave (most blocks of a frame fall into the same few classes).
+constexpr uint32_t kOrderThreads = 1024, kOrderWaves = kOrderThreads / 64;
+__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order)
 {
-	__shared__ uint32_t bins[256];
+	__shared__ uint32_t bins[kOrderWaves][256];
 	__shared__ uint32_t largest;
-	if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+	__shared__ uint32_t waveSum[4];
+	for (uint32_t k = threadIdx.x; k < kOrderWaves * 256u; k += kOrderThreads) (&bins[0][0])[k] = 0;
 	if (threadIdx.x == 0) largest = 1;
 	__syncthreads();
+	// eight elements per step, requested together (one by one, a pass is a chain of dependent round trips)
+	auto forEach = [&](auto body) {
+		for (uint32_t base = 0; base < n; base += 8u * kOrderThreads) {
+			uint32_t c[8];
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++) {
+				const uint32_t i = base + j * kOrderThreads + threadIdx.x;
+				c[j] = i < n ? cost[i] : 0u;
+			}
+#pragma unroll
+			for (uint32_t j = 0; j < 8; j++) {
+				const uint32_t i = base + j * kOrderThreads + threadIdx.x;
+				if (i < n) body(i, c[j]);
+			}
+		}
+	};
 	uint32_t m = 0;
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) m = cost[i] > m ? cost[i] : m;
+	forEach([&](uint32_t, uint32_t c) { m = c > m ? c : m; });
 	atomicMax(&largest, m);
 	__syncthreads();
-	const uint64_t top = largest;
-	auto classOf = [top](uint32_t c) { return 255u - uint32_t(uint64_t(c) * 255u / top); };
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&bins[classOf(cost[i])], 1u);
+	const float scale = 255.0f / float(largest);
+	auto classOf = [scale](uint32_t c) {
+		const uint32_t k = uint32_t(float(c) * scale);
+		return 255u - (k > 255u ? 255u : k);
+	};
+	const uint32_t wave = threadIdx.x >> 6;
+	forEach([&](uint32_t, uint32_t c) { atomicAdd(&bins[wave][classOf(c)], 1u); });
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t at = 0;
-		for (uint32_t k = 0; k < 256; k++) {
-			const uint32_t c = bins[k];
-			bins[k] = at;
-			at += c;
+	// class k of wave w starts behind the classes before k (all waves) and class k of the waves before w
+	uint32_t total = 0, incl = 0;
+	if (threadIdx.x < 256) {
+		for (uint32_t w = 0; w < kOrderWaves; w++) {
+			const uint32_t c = bins[w][threadIdx.x];
+			bins[w][threadIdx.x] = total;
+			total += c;
 		}
+		// prefix sum of the class totals over the 256 classes: a scan inside each of the four waves, then the waves' sums
+		incl = total;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t v = __shfl_up(incl, d, 64);
+			incl += (threadIdx.x & 63u) >= uint32_t(d) ? v : 0u;
+		}
+		if ((threadIdx.x & 63u) == 63u) waveSum[threadIdx.x >> 6] = incl;
 	}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&bins[classOf(cost[i])], 1u)] = i;
+	if (threadIdx.x < 256) {
+		uint32_t before = 0;
+		for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += waveSum[w];
+		const uint32_t start = before + incl - total;
+		for (uint32_t w = 0; w < kOrderWaves; w++) bins[w][threadIdx.x] += start;
+	}
+	__syncthreads();
+	// the same elements go to the same wave as in the counting pass
+	forEach([&](uint32_t i, uint32_t c) { order[atomicAdd(&bins[wave][classOf(c)], 1u)] = i; });
 }
 
 // compact tiles -> full frame (last step of the multi-GPU gather)
@@ -2260,7 +2300,7 @@ __global__ void __launch_bounds__(256) iotaKernel(int32_t *values, uint32_t n)
 }
 extern "C" hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream)
 {
-	hipLaunchKernelGGL(acr::dev::orderBlocksKernel, dim3(1), dim3(1024), 0, stream, cost, n, order);
+	hipLaunchKernelGGL(acr::dev::orderBlocksKernel, dim3(1), dim3(acr::dev::kOrderThreads), 0, stream, cost, n, order);
 	return hipGetLastError();
 }
 
