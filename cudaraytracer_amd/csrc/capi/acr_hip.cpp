@@ -153,7 +153,9 @@ namespace
 #endif
 	constexpr uint32_t kOrderIntervalAfterMove = ACR_ORDER_INTERVAL_AFTER_MOVE;
 	constexpr size_t kLdsBudget = 64 * 1024;
-	constexpr size_t kParallelMaxValues = 1u << 16; // tree nodes of a scene whose plane values are kept for acr_hip_ctx::worldBounds
+	// tree nodes of a scene whose plane values are kept for acr_hip_ctx::worldBounds: every camera change compares the
+	// camera's coordinates with all of them on the host, which must stay negligible next to a frame
+	constexpr size_t kParallelMaxValues = 4096;
 
 	int fail(acr_hip_ctx *ctx, int code, const char *fmt, ...)
 	{
