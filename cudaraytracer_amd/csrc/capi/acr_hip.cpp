@@ -126,6 +126,7 @@ struct acr_hip_ctx
 	size_t blockCap = 0;
 	uint64_t blockKey = 0;      // configuration (frame size, tile list) the order belongs to
 	bool blockOrderValid = false;
+	bool blockCostZero = false;   // blockCost holds zeros (the sort that reads it leaves it so)
 	uint32_t blockOrderAge = 0; // launches since the order was measured
 	void *sortTemp = nullptr;
 	size_t sortTempBytes = 0;
@@ -937,12 +938,14 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 				ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(b), size_t(numBlocks) * sizeof(uint32_t)));
 			ctx->blockCap = numBlocks;
 			ctx->blockOrderValid = false;
+			ctx->blockCostZero = false;
 		}
 		const uint32_t interval = ctx->blockOrderInterval < ctx->blockOrderEvery ? ctx->blockOrderInterval : ctx->blockOrderEvery;
 		measureBlocks = repeated && (!ctx->blockOrderValid || ctx->blockOrderAge + 1 >= interval);
 		if (ctx->blockOrderValid) p.block_order = ctx->blockOrder;
 		if (measureBlocks) {
-			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->blockCost, 0, size_t(numBlocks) * sizeof(uint32_t), ctx->stream));
+			if (!ctx->blockCostZero) ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->blockCost, 0, size_t(ctx->blockCap) * sizeof(uint32_t), ctx->stream));
+			ctx->blockCostZero = false; // until the sort behind this launch has run
 			p.block_cost = ctx->blockCost;
 		}
 	}
@@ -1045,6 +1048,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		if (measureBlocks) {
 			// most expensive first; the launch that was just queued has read the old table by the time this runs
 			ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->stream));
+			ctx->blockCostZero = true;
 			ctx->blockOrderValid = true;
 			ctx->blockOrderAge = 0;
 			if (ctx->blockOrderInterval < (1u << 30)) ctx->blockOrderInterval *= 2;

@@ -2104,7 +2104,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 // make it; frames do not depend on the order at all.  Every wave counts into bins of its own: one LDS atomic per
 // element, contended only inside the wave (most blocks of a frame fall into the same few classes).
 constexpr uint32_t kOrderThreads = 1024, kOrderWaves = kOrderThreads / 64;
-__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(const uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order)
+__global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order)
 {
 	__shared__ uint32_t bins[kOrderWaves][256];
 	__shared__ uint32_t largest;
@@ -2166,7 +2166,11 @@ __global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(const uint32_
 	}
 	__syncthreads();
 	// the same elements go to the same wave as in the counting pass
-	forEach([&](uint32_t i, uint32_t c) { order[atomicAdd(&bins[wave][classOf(c)], 1u)] = i; });
+	// ... and the costs are left at zero for the next measuring launch (which adds to them): no memset in between
+	forEach([&](uint32_t i, uint32_t c) {
+		order[atomicAdd(&bins[wave][classOf(c)], 1u)] = i;
+		cost[i] = 0;
+	});
 }
 
 // compact tiles -> full frame (last step of the multi-GPU gather)
@@ -2298,7 +2302,7 @@ __global__ void __launch_bounds__(256) iotaKernel(int32_t *values, uint32_t n)
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < n) values[i] = int32_t(i);
 }
-extern "C" hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream)
+extern "C" hipError_t acr_dev_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream)
 {
 	hipLaunchKernelGGL(acr::dev::orderBlocksKernel, dim3(1), dim3(acr::dev::kOrderThreads), 0, stream, cost, n, order);
 	return hipGetLastError();

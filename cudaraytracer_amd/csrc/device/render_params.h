@@ -109,7 +109,7 @@ hipError_t acr_dev_launch_reciprocal_check(unsigned long long *differ, hipStream
 hipError_t acr_dev_launch_vote_paths(const uint64_t *keys, int32_t *votes, uint32_t n, int reset, hipStream_t stream);
 hipError_t acr_dev_launch_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n, hipStream_t stream);
 // order[0..n) = the numbers 0..n-1, the ones with the largest cost[] first (256 cost classes)
-hipError_t acr_dev_launch_order_blocks(const uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream);
+hipError_t acr_dev_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream); // leaves cost[0..n) at zero
 hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
                                         uint32_t width, uint32_t height, void *frame, hipStream_t stream);
