@@ -2119,7 +2119,7 @@ __global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(uint32_t *__r
 #pragma unroll
 			for (uint32_t j = 0; j < 8; j++) {
 				const uint32_t i = base + j * kOrderThreads + threadIdx.x;
-				c[j] = i < n ? cost[i] : 0u;
+				c[j] = cost[i < n ? i : n - 1u]; // unconditional: a load under a branch is waited for before the next is requested
 			}
 #pragma unroll
 			for (uint32_t j = 0; j < 8; j++) {
