@@ -433,8 +433,12 @@ def main():
                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_ray": fl / rays0,
                         "kernel": kernel, "kernel_ms": kernel_ms,
                         "frac_of_no_fma_ceiling": tf / (FP32_VECTOR_PEAK_TFLOPS / 2),
-                        "note": "peak counts an FMA as two flops; these kernels are built with -ffp-contract=off (the checker's arithmetic), "
-                                "so no FMA issues and %.1f TFLOP/s is the most they could reach" % (FP32_VECTOR_PEAK_TFLOPS / 2)}
+                        "frac_of_unpacked_no_fma_ceiling": tf / (FP32_VECTOR_PEAK_TFLOPS / 4),
+                        "note": "peak counts an FMA as two flops and two packed operations per lane and cycle (v_pk_fma_f32); these "
+                                "kernels are built with -ffp-contract=off (the checker's arithmetic), so no FMA issues and %.1f TFLOP/s "
+                                "is the most they could reach with every operation packed, %.1f with the one-operation-per-lane "
+                                "instructions a divergent traversal issues"
+                                % (FP32_VECTOR_PEAK_TFLOPS / 2, FP32_VECTOR_PEAK_TFLOPS / 4)}
                 if lds_mode != 2:
                     # nodes and triangles are read from HBM: count them at the reference's record sizes
                     per_ray = (NODE_BYTES * counters["node_visits"] + TRIANGLE_BYTES * counters["triangle_tests"]) / rays0
