@@ -10,7 +10,10 @@ environment): the image is cut into tiles, each rank renders a contiguous run
 of tiles, rank 0 gathers them over RCCL and assembles the frame.
 
 A step is one frame: a fresh seed, frames = 0 (what the reference renders
-after every camera move).  Rank 0 prints one JSON line.  On one GPU the line
+after every camera move).  Rank 0 prints one JSON line.  On one GPU the W
+warm-up steps are preceded by --settle-ms (default 30) of untimed frames that
+bring the GPU's clocks up from the idle state the scene set-up left them in;
+the line reports their number as settle_frames.  On one GPU the line
 also carries the roofline of the render kernel (timed with HIP events on the
 stream it is launched on) and a CPU baseline: the oracle (this repository's
 CPU restatement of the reference algorithm) timed on the host cores on a
@@ -200,6 +203,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--block-order-every", type=int, default=None, help="longest interval between block-order measurements (library default 64; 0 = natural order)")
+    ap.add_argument("--settle-ms", type=float, default=30.0, help="one GPU: render untimed frames for this long before the warm-up, so that the "
+                    "GPU's clocks have come up from idle (0 = none)")
     ap.add_argument("--no-also", action="store_true", help="several GPUs: do not run the compute-heavy workloads (c3, c4) after the headline one")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -262,6 +267,18 @@ def main():
             core.render(WIDTH, HEIGHT, seed=seed0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr)
             step_no[0] += 1
 
+        # The GPU idles while the host builds and uploads the scene, and after an idle period its clocks take some
+        # 20 ms of rendering to come back up (Cornell 1080p frames launched after 50 ms of idling: 0.160 ms each at
+        # first, 0.154 after 40 frames, 0.146 after 120; a synchronize alone does not cause it).  A renderer in use
+        # is never in that state, so untimed frames are rendered for SETTLE_MS before the W warm-up steps; the
+        # line reports how many (settle_frames).  They use seeds of their own and leave step_no alone.
+        settle_frames = 0
+        t_settle = time.perf_counter()
+        while args.settle_ms > 0 and 1e3 * (time.perf_counter() - t_settle) < args.settle_ms:
+            for k in range(10):
+                core.render(WIDTH, HEIGHT, seed=seed0 - 1 - settle_frames, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr)
+                settle_frames += 1
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         barrier()
@@ -327,6 +344,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_frames": settle_frames if world == 1 else None,  # untimed frames before the warm-up that bring the GPU's clocks up from idle (--settle-ms)
             "ms_per_step": ms,
             "ms_per_frame": ms,
             "rays_per_frame": rays / args.steps,
