@@ -7,12 +7,14 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/acr_hip.h"
@@ -123,6 +125,10 @@ struct acr_hip_ctx
 	uint32_t blockOrderEvery = 64;   // longest interval between two measurements, in launches; 0 = natural order
 	uint32_t blockOrderInterval = 4; // current interval: 4 after a camera move, doubling while the view stays
 	uint32_t *blockCost = nullptr, *blockOrder = nullptr;
+	// the blocks of the current full-frame size along their Z-curve, for the XCD-aware order of scenes read through the L2
+	uint32_t *blockZ = nullptr;
+	uint32_t blockZCount = 0, blockZBlocksX = 0;
+	std::vector<uint32_t> blockZHost;
 	size_t blockCap = 0;
 	uint64_t blockKey = 0;      // configuration (frame size, tile list) the order belongs to
 	bool blockOrderValid = false;
@@ -427,6 +433,7 @@ void acr_hip_destroy(acr_hip_ctx *ctx)
 	(void)hipFree(ctx->meshGlob);
 	(void)hipFree(ctx->blockCost);
 	(void)hipFree(ctx->blockOrder);
+	(void)hipFree(ctx->blockZ);
 	(void)hipFree(ctx->sortTemp);
 	(void)hipFree(ctx->sortKeysOut);
 	(void)hipFree(ctx->sortValuesIn);
@@ -929,12 +936,13 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		}
 		if (ctx->blockCap < numBlocks) {
 			ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder}) {
+			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder, &ctx->blockZ}) {
 				(void)hipFree(*b);
 				*b = nullptr;
 			}
 			ctx->blockCap = 0;
-			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder})
+			ctx->blockZCount = 0;
+			for (uint32_t **b : {&ctx->blockCost, &ctx->blockOrder, &ctx->blockZ})
 				ACR_HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(b), size_t(numBlocks) * sizeof(uint32_t)));
 			ctx->blockCap = numBlocks;
 			ctx->blockOrderValid = false;
@@ -1047,7 +1055,30 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	if (ownOrder) {
 		if (measureBlocks) {
 			// most expensive first; the launch that was just queued has read the old table by the time this runs
-			ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->stream));
+			// Scenes whose trees and triangles are read through the L2 get the XCD-aware table: the blocks one XCD
+			// renders are neighbours in the frame (10 M-triangle soup: 2.55 -> 2.46 ms per frame; a scene resident in
+			// LDS has nothing in the L2 to share and loses balance by it: Cornell 1080p 0.151 -> 0.170 ms).
+			if (!tiled && plan.ldsMode != 2) {
+				const uint32_t bx = (f->width + 15) / 16;
+				if (ctx->blockZCount != numBlocks || ctx->blockZBlocksX != bx) {
+					auto spread = [](uint32_t v) { // bit k of v to bit 2k
+						uint64_t r = 0;
+						for (uint32_t k = 0; k < 32; k++) r |= uint64_t((v >> k) & 1u) << (2 * k);
+						return r;
+					};
+					std::vector<std::pair<uint64_t, uint32_t>> keyed(numBlocks);
+					for (uint32_t b = 0; b < numBlocks; b++) keyed[b] = {spread(b % bx) | (spread(b / bx) << 1), b};
+					std::sort(keyed.begin(), keyed.end());
+					ctx->blockZHost.resize(numBlocks);
+					for (uint32_t b = 0; b < numBlocks; b++) ctx->blockZHost[b] = keyed[b].second;
+					ACR_HIP_TRY(ctx, hipMemcpyAsync(ctx->blockZ, ctx->blockZHost.data(), size_t(numBlocks) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+					ctx->blockZCount = numBlocks;
+					ctx->blockZBlocksX = bx;
+				}
+				ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks_regions(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->blockZ, ctx->stream));
+			} else {
+				ACR_HIP_TRY(ctx, acr_dev_launch_order_blocks(ctx->blockCost, numBlocks, ctx->blockOrder, ctx->stream));
+			}
 			ctx->blockCostZero = true;
 			ctx->blockOrderValid = true;
 			ctx->blockOrderAge = 0;

@@ -2173,6 +2173,110 @@ __global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(uint32_t *__r
 	});
 }
 
+// The same table for scenes whose trees and triangles are read through the L2: XCD-aware.  Workgroups are dealt
+// round-robin over the GPU's XCDs, so table position i is rendered on XCD i % kXcds, and every XCD has an L2 of its
+// own.  The blocks' Z-curve (zseq, made by the host) is cut into kXcds runs of equal measured cost, run g is sorted
+// most expensive first and laid out on positions g, g + kXcds, ...: the workgroups that share an L2 then walk
+// neighbouring parts of the trees at the same time.  A run with more blocks than its XCD has positions (cheap
+// blocks) hands its cheapest ones to the positions that the runs with few, expensive blocks leave free at their
+// XCDs' ends.  One workgroup; thread t owns a stretch of the Z-curve.  Leaves cost[] at zero like orderBlocksKernel.
+constexpr uint32_t kXcds = 8;
+__global__ void __launch_bounds__(kOrderThreads) orderBlocksRegionsKernel(uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order,
+                                                                          const uint32_t *__restrict__ zseq)
+{
+	__shared__ unsigned long long partial[kOrderThreads];
+	__shared__ uint32_t bins[kXcds][256];
+	__shared__ uint32_t largest;
+	__shared__ uint32_t runCount[kXcds], overflowStart[kXcds + 1], freeStart[kXcds + 1];
+	for (uint32_t k = threadIdx.x; k < kXcds * 256u; k += kOrderThreads) (&bins[0][0])[k] = 0;
+	if (threadIdx.x == 0) largest = 1;
+	__syncthreads();
+	const uint32_t chunk = (n + kOrderThreads - 1u) / kOrderThreads;
+	const uint32_t lo = threadIdx.x * chunk < n ? threadIdx.x * chunk : n;
+	const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+	unsigned long long sum = 0;
+	uint32_t m = 0;
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint32_t c = cost[zseq[i]];
+		sum += c;
+		m = c > m ? c : m;
+	}
+	partial[threadIdx.x] = sum;
+	atomicMax(&largest, m);
+	__syncthreads();
+	unsigned long long before = 0, total = 0;
+	for (uint32_t t = 0; t < kOrderThreads; t++) {
+		const unsigned long long v = partial[t];
+		before += t < threadIdx.x ? v : 0ull;
+		total += v;
+	}
+	if (total == 0) total = 1;
+	const float scale = 255.0f / float(largest);
+	auto classOf = [scale](uint32_t c) {
+		const uint32_t k = uint32_t(float(c) * scale);
+		return 255u - (k > 255u ? 255u : k);
+	};
+	// the run of a block: where the middle of its cost lies in the whole, in eighths
+	auto runOf = [total](unsigned long long prefix, uint32_t c) {
+		const uint32_t g = uint32_t((kXcds * (prefix + c / 2u)) / total);
+		return g < kXcds ? g : kXcds - 1u;
+	};
+	{
+		unsigned long long prefix = before;
+		for (uint32_t i = lo; i < hi; i++) {
+			const uint32_t c = cost[zseq[i]];
+			atomicAdd(&bins[runOf(prefix, c)][classOf(c)], 1u);
+			prefix += c;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < kXcds) {
+		uint32_t at = 0;
+		for (uint32_t k = 0; k < 256u; k++) {
+			const uint32_t c = bins[threadIdx.x][k];
+			bins[threadIdx.x][k] = at;
+			at += c;
+		}
+		runCount[threadIdx.x] = at;
+	}
+	__syncthreads();
+	auto slotsOf = [n](uint32_t g) { return g < n ? (n - g + kXcds - 1u) / kXcds : 0u; }; // positions g, g + kXcds, ... below n
+	if (threadIdx.x == 0) {
+		uint32_t ov = 0, fr = 0;
+		for (uint32_t g = 0; g < kXcds; g++) {
+			overflowStart[g] = ov;
+			freeStart[g] = fr;
+			const uint32_t have = runCount[g], room = slotsOf(g);
+			ov += have > room ? have - room : 0u;
+			fr += room > have ? room - have : 0u;
+		}
+		overflowStart[kXcds] = ov;
+		freeStart[kXcds] = fr;
+	}
+	__syncthreads();
+	{
+		unsigned long long prefix = before;
+		for (uint32_t i = lo; i < hi; i++) {
+			const uint32_t b = zseq[i];
+			const uint32_t c = cost[b];
+			const uint32_t g = runOf(prefix, c);
+			prefix += c;
+			const uint32_t r = atomicAdd(&bins[g][classOf(c)], 1u);
+			uint32_t pos;
+			if (r < slotsOf(g)) {
+				pos = kXcds * r + g;
+			} else {
+				const uint32_t ov = overflowStart[g] + (r - slotsOf(g));
+				uint32_t h = 0;
+				while (h + 1u < kXcds && freeStart[h + 1u] <= ov) h++;
+				pos = kXcds * (runCount[h] + (ov - freeStart[h])) + h;
+			}
+			order[pos] = b;
+			cost[b] = 0;
+		}
+	}
+}
+
 // compact tiles -> full frame (last step of the multi-GPU gather)
 __global__ void __launch_bounds__(kBlock) scatterTilesKernel(const float4 *__restrict__ tiles, const uint32_t *__restrict__ tileIds,
                                                              uint32_t tileW, uint32_t tileH, uint32_t tilesX, uint32_t width, uint32_t height,
@@ -2251,6 +2355,12 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
 	return launchWithLds(kl, *p, kRedoGrid, ldsBytes, stream);
+}
+
+extern "C" hipError_t acr_dev_launch_order_blocks_regions(uint32_t *cost, uint32_t n, uint32_t *order, const uint32_t *zseq, hipStream_t stream)
+{
+	hipLaunchKernelGGL(acr::dev::orderBlocksRegionsKernel, dim3(1), dim3(acr::dev::kOrderThreads), 0, stream, cost, n, order, zseq);
+	return hipGetLastError();
 }
 
 extern "C" hipError_t acr_dev_launch_render(const acr::dev::RenderParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream)

@@ -110,6 +110,9 @@ hipError_t acr_dev_launch_vote_paths(const uint64_t *keys, int32_t *votes, uint3
 hipError_t acr_dev_launch_vote_keys(const int32_t *votes, uint64_t *keys, uint32_t n, hipStream_t stream);
 // order[0..n) = the numbers 0..n-1, the ones with the largest cost[] first (256 cost classes)
 hipError_t acr_dev_launch_order_blocks(uint32_t *cost, uint32_t n, uint32_t *order, hipStream_t stream); // leaves cost[0..n) at zero
+// the same, XCD-aware: position i of order[] is taken to run on XCD i % 8, and the blocks of one XCD are neighbours on
+// the Z-curve zseq[0..n) (a permutation of 0..n-1), most expensive first
+hipError_t acr_dev_launch_order_blocks_regions(uint32_t *cost, uint32_t n, uint32_t *order, const uint32_t *zseq, hipStream_t stream);
 hipError_t acr_dev_launch_trace(const acr::dev::TraceParams *p, int ldsMode, int fast, uint32_t grid, size_t ldsBytes, hipStream_t stream);
 hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint32_t *tileIdsDev, uint32_t numTiles, uint32_t tileW, uint32_t tileH,
                                         uint32_t width, uint32_t height, void *frame, hipStream_t stream);

@@ -729,6 +729,29 @@ def test_block_launch_order_does_not_change_frames(core, built, acr):
     core.set_block_order(64)
 
 
+def test_block_launch_order_of_a_scene_read_through_the_l2(core, acr, orc):
+    """A scene whose trees are not LDS-resident gets the XCD-aware order table (runs of the blocks' Z-curve of
+    equal measured cost, one per XCD, most expensive first inside, overflow into the positions other runs leave
+    free).  The table must hold every block exactly once whatever the costs: frames of a size with cut-off edge
+    blocks, a new seed on every launch so that a block left out would show, each equal to the oracle's; then
+    another size on the same context (the Z-curve is rebuilt)."""
+    b = Built(acr, orc, soup_data(acr, 60000, seed=9, edge=0.1, extent=1.0), mesh_depth=14)
+    load(core, b)
+    core.set_block_order(4)
+    try:
+        for (w, h), launches in (((650, 470), 8), ((1000, 330), 4)):   # 41 x 30 and 63 x 21 blocks of 16 x 16
+            seen = []
+            for k in range(launches):
+                ref = b.oracle.render(w, h, seed=30 + k, frames=0, max_bounces=1)
+                img, pid, ht, st = render(core, w, h, seed=30 + k, frames=0, max_bounces=1)
+                assert st.scene_in_lds != 2
+                seen.append(st.block_order)
+                assert_same(img, pid, ht, st, ref)
+            assert seen == [0, 0] + [1] * (launches - 2)
+    finally:
+        core.set_block_order(64)
+
+
 def test_accumulating_ray_counters(core, built):
     """collect_stats = 2 keeps what earlier launches counted: three frames, one read, the oracle's three totals."""
     b = built["cornell-box-cycles"]

@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=None)
-    ap.add_argument("--block-order", choices=["natural", "heavy-first", "reverse"], default="natural")
+    ap.add_argument("--block-order", choices=["natural", "heavy-first", "reverse", "xcd-regions"], default="natural")
     ap.add_argument("--scene", default="cornell-box-cycles")
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--bounces", type=int, default=1)
@@ -101,7 +101,35 @@ def main():
                     screen_dev=C.c_void_p(tiles.data_ptr()), tile_cycles_dev=C.c_void_p(cyc.data_ptr()))
         core.sync()
         cost = cyc.cpu().numpy().astype(np.int64)
-        order = np.argsort(-cost, kind="stable") if args.block_order == "heavy-first" else np.arange(nb)[::-1].copy()
+        if args.block_order == "xcd-regions":
+            # Workgroups are dealt round-robin over the 8 XCDs, so table position i is rendered on XCD i % 8: give every
+            # XCD a compact region of the image (a run of the blocks' Z-curve holding an eighth of the measured cost),
+            # most expensive first inside it, so that the workgroups that share an L2 walk neighbouring parts of the trees.
+            ys, xs = np.divmod(np.arange(nb), bx)
+            def spread(v):
+                v = v.astype(np.uint64)
+                r = np.zeros_like(v)
+                for bit in range(16):
+                    r |= ((v >> np.uint64(bit)) & np.uint64(1)) << np.uint64(2 * bit)
+                return r
+            z = np.argsort(spread(xs) | (spread(ys) << np.uint64(1)), kind="stable")
+            cum = np.cumsum(cost[z]) - cost[z] * 0.5
+            grp = np.minimum((8 * cum / max(1, cost.sum())).astype(np.int64), 7)
+            lists = [list(z[grp == g][np.argsort(-cost[z[grp == g]], kind="stable")]) for g in range(8)]
+            heads = [0] * 8
+            out = []
+            while len(out) < nb:
+                for g in range(8):
+                    if len(out) >= nb:
+                        break
+                    if heads[g] >= len(lists[g]):
+                        g = max(range(8), key=lambda k: len(lists[k]) - heads[k])  # this XCD's region is done: help the one with most left
+                    out.append(lists[g][heads[g]])
+                    heads[g] += 1
+            order = np.array(out, dtype=np.int64)
+            assert len(np.unique(order)) == nb
+        else:
+            order = np.argsort(-cost, kind="stable") if args.block_order == "heavy-first" else np.arange(nb)[::-1].copy()
         order_dev = torch.from_numpy(order.astype(np.int32)).to(dev)
         kw["block_order_dev"] = C.c_void_p(order_dev.data_ptr())
         core.render(w, h, seed=777, frames=0, max_bounces=args.bounces, **kw)
