@@ -92,8 +92,8 @@ struct acr_hip_ctx
 	// Primary rays parallel to a coordinate plane (a direction component of exactly zero, 1 / d infinite): the interval
 	// form serves them too when no plane or box bound they can meet on that axis equals the camera's coordinate there
 	// (then no 0 * infinity, hence no NaN, can arise, and infinite slab distances compare like the reference's).
-	// Kept per axis for the tree over objects and per object (in its local space) for its mesh trees; scenes with
-	// more than kParallelMaxObjects objects or kParallelMaxValues such values go without.
+	// Kept per axis, sorted, for the tree over objects and per object (in its local space) for its mesh trees; scenes
+	// with more than kParallelMaxObjects objects go without.
 	struct AxisValues
 	{
 		std::vector<float> v[3];
@@ -160,9 +160,6 @@ namespace
 #endif
 	constexpr uint32_t kOrderIntervalAfterMove = ACR_ORDER_INTERVAL_AFTER_MOVE;
 	constexpr size_t kLdsBudget = 64 * 1024;
-	// tree nodes of a scene whose plane values are kept for acr_hip_ctx::worldBounds: every camera change compares the
-	// camera's coordinates with all of them on the host, which must stay negligible next to a frame
-	constexpr size_t kParallelMaxValues = 4096;
 
 	int fail(acr_hip_ctx *ctx, int code, const char *fmt, ...)
 	{
@@ -706,7 +703,7 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	ctx->parallelBitsValid = false;
 	ctx->worldBounds = acr_hip_ctx::AxisValues();
 	ctx->localSpaces.clear();
-	if (intervalOk && s->num_objects <= acr::dev::kParallelMaxObjects && size_t(snodeCount) + packedMeshNodes <= kParallelMaxValues) {
+	if (intervalOk && s->num_objects <= acr::dev::kParallelMaxObjects) {
 		auto planes = [](acr_hip_ctx::AxisValues &out, const float *left, const float *right, const uint8_t *flags, uint32_t count) {
 			for (uint32_t i = 0; i < count; i++) {
 				if (flags[i] & ACR_NODE_LEAF) continue;
@@ -745,6 +742,16 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 				planes(ls.bounds, s->mnode_left + nb, s->mnode_right + nb, s->mnode_flags + nb, (1u << meshLevels[m]) - 1);
 			}
 		}
+		// sorted, each value once: the per-camera look-up is a binary search whatever the scene's size
+		auto tidy = [](acr_hip_ctx::AxisValues &b) {
+			for (std::vector<float> &v : b.v) {
+				std::sort(v.begin(), v.end());
+				v.erase(std::unique(v.begin(), v.end()), v.end());
+				v.shrink_to_fit();
+			}
+		};
+		tidy(ctx->worldBounds);
+		for (acr_hip_ctx::LocalSpace &ls : ctx->localSpaces) tidy(ls.bounds);
 		ctx->parallelOk = true;
 	}
 
@@ -881,8 +888,9 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		auto clear = [](const acr_hip_ctx::AxisValues &b, const vec3 &o) {
 			uint32_t bits = 0;
 			for (int a = 0; a < 3; a++) {
-				bool hit = false;
-				for (float v : b.v[a]) hit = hit || v == o[a];
+				bool hit;
+				// the values are sorted (upload): equal to o[a] iff neither is less than the other; +0 and -0 count as equal, as with ==
+				hit = std::binary_search(b.v[a].begin(), b.v[a].end(), o[a]);
 				if (!hit) bits |= 1u << a;
 			}
 			return bits;

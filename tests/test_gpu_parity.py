@@ -247,6 +247,30 @@ def test_primary_rays_parallel_to_a_coordinate_plane(core, built, acr, orc):
         assert_same(img, pid, ht, st, tri.oracle.render(640, 480, seed=seed, frames=0, max_bounces=1))
 
 
+def test_parallel_primary_rays_on_a_scene_read_from_hbm(core, acr, orc):
+    """The same for a scene whose mesh tree (16 383 nodes, depth 14) is read from HBM and walked near side first: the
+    plane values are kept sorted per axis, so the launch vouches for a tree of any size.  With an axis-aligned camera
+    in front of the soup these seeds each send one primary ray with a direction component of exactly zero; they used
+    to go to the six-plane pass (whole-tree walks in the reference's order) and are now served by the interval form.
+    Frames, ids and distances equal the six-plane kernel's, and the oracle's."""
+    b = Built(acr, orc, soup_data(acr, 60000, seed=9, edge=0.1, extent=1.0), mesh_depth=14)
+    load(core, b)
+    w, h = 1920, 1080
+    for seed in (205, 209, 215, 301, 306):
+        img, pid, ht, st = render(core, w, h, seed=seed, frames=0, max_bounces=1)
+        assert st.near_first == 1 and st.six_plane_pixels == 0
+        core.set_traversal(six_plane_only=True)
+        try:
+            img6, pid6, ht6, st6 = render(core, w, h, seed=seed, frames=0, max_bounces=1)
+        finally:
+            core.set_traversal(six_plane_only=False)
+        assert st6.interval_traversal == 0
+        assert np.array_equal(img.view(np.uint32), img6.view(np.uint32)) and np.array_equal(pid, pid6)
+        assert np.array_equal(ht.view(np.uint32), ht6.view(np.uint32))
+        if seed in (205, 306):
+            assert_same(img, pid, ht, st, b.oracle.render(w, h, seed=seed, frames=0, max_bounces=1))
+
+
 def test_scene_with_a_gigantic_triangle_keeps_the_division(core, acr, orc):
     """The interval-form kernels take the determinant's reciprocal without dividing, which is the quotient only up to
     |det| = 2^126; a scene is given to them only if |e1| |e2| < 2^120 for every triangle.  One triangle with edges of
