@@ -1074,6 +1074,8 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 						for (uint32_t k = 0; k < 32; k++) r |= uint64_t((v >> k) & 1u) << (2 * k);
 						return r;
 					};
+					// the host copy below may still be the source of the last upload: a new frame size is rare enough to wait
+					ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 					std::vector<std::pair<uint64_t, uint32_t>> keyed(numBlocks);
 					for (uint32_t b = 0; b < numBlocks; b++) keyed[b] = {spread(b % bx) | (spread(b / bx) << 1), b};
 					std::sort(keyed.begin(), keyed.end());
