@@ -1066,8 +1066,10 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 			// Scenes whose trees and triangles are read through the L2 get the XCD-aware table: the blocks one XCD
 			// renders are neighbours in the frame (10 M-triangle soup: 2.55 -> 2.46 ms per frame; a scene resident in
 			// LDS has nothing in the L2 to share and loses balance by it: Cornell 1080p 0.151 -> 0.170 ms).
-			if (!tiled && plan.ldsMode != 2) {
-				const uint32_t bx = (f->width + 15) / 16;
+			// A list of full-width bands of 16 rows (the multi-GPU split) numbers its blocks row by row like a frame
+			// of its own; other tile lists keep the plain order.
+			const uint32_t bx = !tiled ? (f->width + 15) / 16 : ((f->tile_h == 16 && f->tile_w >= f->width) ? f->tile_w >> 4 : 0u);
+			if (bx != 0 && plan.ldsMode != 2) {
 				if (ctx->blockZCount != numBlocks || ctx->blockZBlocksX != bx) {
 					auto spread = [](uint32_t v) { // bit k of v to bit 2k
 						uint64_t r = 0;

@@ -222,7 +222,8 @@ int acr_hip_selftest_reciprocal(acr_hip_ctx *ctx, uint64_t *mismatches);
  * camera keeps the table and puts the interval back to 4.  This is the reference's adaptive assignment (a table
  * consulted by the kernel, rebuilt from measured history on a cadence, reconsidered when the camera moves:
  * renderer.cu:343-355,457-461,165) applied to the order of workgroups; frames do not depend on it.
- * For full-frame launches of a scene whose trees are read from device memory the table is also XCD-aware: the
+ * For full-frame launches (and lists of full-width bands of 16 rows) of a scene whose trees are read from device
+ * memory the table is also XCD-aware: the
  * blocks one XCD's workgroups render are neighbours in the frame (runs of the blocks' Z-curve of equal measured
  * cost, most expensive first inside each), so that the workgroups sharing an L2 walk the same parts of the trees.
  * every == 0: natural order.  acr_frame::block_order_dev overrides it for one launch. */

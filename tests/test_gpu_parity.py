@@ -772,6 +772,22 @@ def test_block_launch_order_of_a_scene_read_through_the_l2(core, acr, orc):
                 seen.append(st.block_order)
                 assert_same(img, pid, ht, st, ref)
             assert seen == [0, 0] + [1] * (launches - 2)
+        # a list of full-width bands (the multi-GPU split) gets the same kind of table: 20 bands of 64 blocks
+        import torch
+        w, h = 1024, 320
+        ids = np.arange(h // 16, dtype=np.uint32)
+        tiles = torch.zeros((len(ids), 16 * w, 4), dtype=torch.float32, device="cuda")
+        core.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            for k in range(5):
+                core.render(w, h, seed=50 + k, frames=0, max_bounces=1, tile_ids=ids, tile_w=w, tile_h=16,
+                            screen_dev=C.c_void_p(tiles.data_ptr()), collect_stats=True)
+                core.sync()
+                assert core.read_stats().block_order == (1 if k >= 2 else 0)
+                ref = b.oracle.render(w, h, seed=50 + k, frames=0, max_bounces=1, aov=False)
+                assert np.array_equal(tiles.cpu().numpy().reshape(h, w, 4).view(np.uint32), ref["screen"].view(np.uint32))
+        finally:
+            core.use_own_stream()
     finally:
         core.set_block_order(64)
 
