@@ -9,8 +9,15 @@ torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
 environment): the image is cut into tiles, each rank renders a contiguous run
 of tiles, rank 0 gathers them over RCCL and assembles the frame.
 
-A step is one frame: a fresh seed, frames = 0 (what the reference renders
-after every camera move).  Rank 0 prints one JSON line.  On one GPU the W
+A step is one frame with a fresh seed.  --mode still (the default) is the
+reference's own protocol, the one its only instrumentation times ("Time for 200
+frames", renderer.cu:399-406): the camera stands still and frame k is averaged
+into the framebuffer with frames = k (renderer.cu:375-387); across GPUs every
+rank keeps the running mean of its own bands and the pieces travel to GPU 0
+when the frame is read, once, at the end of the timed region (inside it).
+--mode moving renders every step with frames = 0, as after a camera move
+(renderer.cu:165), and across GPUs assembles every frame on GPU 0; c5, the
+flythrough, always runs that way.  Rank 0 prints one JSON line.  On one GPU the W
 warm-up steps are preceded by --settle-ms (default 30) of untimed frames that
 bring the GPU's clocks up from the idle state the scene set-up left them in;
 the line reports their number as settle_frames.  On one GPU the line
@@ -52,9 +59,9 @@ NODE_BYTES, TRIANGLE_BYTES = 20, 36   # reference record sizes: BIH node (bih.h:
 
 WORKLOADS = {
     "c2": dict(scene="cornell-box-cycles", width=1920, height=1080, bounces=1,
-               text="C2: cornell-box-cycles 1920x1080, primary + shadow rays (max_bounces 1), frames=0 every step"),
+               text="C2: cornell-box-cycles 1920x1080, primary + shadow rays (max_bounces 1)"),
     "c3": dict(scene="cornell-box-cycles", width=3840, height=2160, bounces=4,
-               text="C3: cornell-box-cycles 3840x2160, max_bounces 4, frames=0 every step"),
+               text="C3: cornell-box-cycles 3840x2160, max_bounces 4"),
     "c4": dict(soup=10_000_000, depth=22, edge=0.1, extent=10.0, width=1920, height=1080, bounces=1,
                text="C4: procedural soup, 10 M triangles (centres in [-10,10]^3, edges in [-0.1,0.1]^3, seed 1), mesh BIH depth 22, "
                     "1920x1080, primary + shadow rays"),
@@ -118,7 +125,7 @@ class Workload:
 SEED0 = 12345
 
 
-def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
+def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier, still):
     """The frame split over the ranks of the process group: `warmup` untimed frames, `steps` timed ones between
     barriers, then the rays of the timed frames (counted afterwards) and, on rank 0, the last assembled frame
     against one full-frame render of the same seed and camera.  Returns a dict; elapsed is this rank's."""
@@ -128,6 +135,7 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
     def frame_args():
         if w.cameras:
             core.set_camera(w.camera_of(step_no[0]))
+        # still: the renderer passes the frame count of its running mean; this entry is what a moving camera renders with
         a = dict(seed=SEED0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES)
         step_no[0] += 1
         return a
@@ -135,12 +143,12 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
     render_bands = D.hip_render_tiles(core, WIDTH, HEIGHT, TILE_W, TILE_H, frame_args, cost_kind="cycles")
     dr = D.DistributedRenderer(WIDTH, HEIGHT, render_bands, device,
                                tile_w=TILE_W, tile_h=TILE_H, scatter=D.hip_scatter(core, WIDTH, HEIGHT, TILE_W, TILE_H),
-                               rebalance_every=1 if w.cameras else 16, stage_through_host=rehearsal)
+                               rebalance_every=1 if w.cameras else 16, stage_through_host=rehearsal, accumulate=still)
     # Shares of the frame from measured speed (untimed, before the warm-up): a rank that has to send its piece
     # over one xGMI link finishes fewer bands per second than rank 0, which only renders.  Three times: the
     # later calls fit each phase's fixed cost and cost per band through two measurements at different shares.
     cal = None
-    if os.environ.get("ACR_BENCH_EQUAL_SHARES") != "1":
+    if not still and os.environ.get("ACR_BENCH_EQUAL_SHARES") != "1":
         dr.render_frame()
         dr.finish()
         for _ in range(3):
@@ -148,6 +156,9 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
         if rank == 0 and cal:
             print("[shares %s] render ms %s send ms %s shares %s" % (w.name, [round(1e3 * float(x), 3) for x in cal["render_s"]],
                   [round(1e3 * float(x), 3) for x in cal["send_s"]], [round(float(x), 3) for x in cal["weights"]]), file=sys.stderr)
+    if still:
+        dr.camera_moved()  # the running mean starts with the first warm-up frame
+    first_frame = step_no[0]
     for _ in range(warmup):
         dr.render_frame()
     dr.finish()
@@ -156,7 +167,7 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
     t0 = time.perf_counter()
     for _ in range(steps):
         dr.render_frame()
-    dr.finish()
+    dr.finish()  # still: this is where the pieces travel to GPU 0, once
     barrier()
     elapsed = time.perf_counter() - t0
     # functional check, outside the timed region: the last assembled frame against one full-frame render
@@ -165,7 +176,10 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
         last = step_no[0] - 1
         full = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=device)
         core.set_camera(w.camera_of(last))
-        core.render(WIDTH, HEIGHT, seed=SEED0 + last, frames=0, max_bounces=MAX_BOUNCES, screen_dev=C.c_void_p(full.data_ptr()))
+        # still: the same running mean on one GPU, frame by frame from the first warm-up frame on
+        for k in (range(first_frame, last + 1) if still else (last, )):
+            core.render(WIDTH, HEIGHT, seed=SEED0 + k, frames=k - first_frame if still else 0, max_bounces=MAX_BOUNCES,
+                        screen_dev=C.c_void_p(full.data_ptr()))
         torch.cuda.synchronize()
         same = bool(torch.equal(full.view(torch.int32), dr.frame.view(torch.int32)))
         print(f"[check {w.name}] assembled frame equals single-GPU frame: {same}; split {[int(x) for x in dr.plan.begin]}", file=sys.stderr)
@@ -177,6 +191,8 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier):
     # counts switched on (the total does not depend on how the frame is split)
     ray_sums = []
     dr.settle()
+    if still:
+        dr.camera_moved()
     dr.rebalance_every = 0
     render_bands.cost_kind = "rays"
     step_no[0] = first_timed
@@ -205,11 +221,15 @@ def main():
     ap.add_argument("--block-order-every", type=int, default=None, help="longest interval between block-order measurements (library default 64; 0 = natural order)")
     ap.add_argument("--settle-ms", type=float, default=30.0, help="one GPU: render untimed frames for this long before the warm-up, so that the "
                     "GPU's clocks have come up from idle (0 = none)")
+    ap.add_argument("--mode", choices=("still", "moving"), default="still",
+                    help="still: the camera stands still, frame k is averaged into the framebuffer with frames = k (the reference's "
+                         "render loop); moving: every step renders with frames = 0, as after a camera move")
     ap.add_argument("--no-also", action="store_true", help="several GPUs: do not run the compute-heavy workloads (c3, c4) after the headline one")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     WIDTH, HEIGHT, MAX_BOUNCES = wl["width"], wl["height"], wl["bounces"]
     heavy = args.workload in ("c3", "c4")
+    still = args.mode == "still" and "flythrough" not in wl  # a flythrough moves the camera on every frame
     if args.steps is None:
         args.steps = 30 if heavy else 200
     if args.warmup is None:
@@ -255,16 +275,18 @@ def main():
         torch.cuda.synchronize()
 
     kernel_ms = None
+    extra = {}
     multi = None
     also = []
     if world == 1:
         screen = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=device)
         ptr = C.c_void_p(screen.data_ptr())
 
-        def step():
+        def step(mode_still=still, stats=0):
             if cameras:
                 core.set_camera(camera_of(step_no[0]))
-            core.render(WIDTH, HEIGHT, seed=seed0 + step_no[0], frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr)
+            core.render(WIDTH, HEIGHT, seed=seed0 + step_no[0], frames=step_no[0] if mode_still else 0, max_bounces=MAX_BOUNCES, screen_dev=ptr,
+                        collect_stats=stats)
             step_no[0] += 1
 
         # The GPU idles while the host builds and uploads the scene, and after an idle period its clocks take some
@@ -283,32 +305,65 @@ def main():
             step()
         barrier()
         first_timed = step_no[0]
-        # HIP events around every 7th step only (a stride that does not lock onto the 16-launch cadence of the block-order measurement): an event costs the stream several microseconds, which is
-        # visible against a 0.2 ms frame
-        evs = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in range(0, args.steps, 7)}
+        # the timed region: K asynchronous launches back to back, nothing else on the stream, one barrier at the end
         t0 = time.perf_counter()
         for k in range(args.steps):
-            if k in evs:
-                evs[k][0].record()
-                step()
-                evs[k][1].record()
-            else:
-                step()
+            step()
         barrier()
         elapsed = time.perf_counter() - t0
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs.values()]))
+        last_timed = step_no[0]
+
+        # ---- further passes over the same kind of step, none of them part of `value` ----
+        extra = {}
+        n_ev = max(args.steps, 10)
+        # (a) every step between two HIP events on the stream the kernels run on: per-step times, their mean and median
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        barrier()
+        per_step = [a.elapsed_time(b) for a, b in evs]
+        extra["step_ms"] = float(np.mean(per_step))
+        extra["ms_per_step_median"] = float(np.median(per_step))
+        extra["step_ms_samples"] = n_ev
+        # (b) the reference's protocol: the host waits for every frame before it starts the next (renderer.cu:421-422)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+            torch.cuda.synchronize()
+        extra["ms_per_frame_synced"] = 1e3 * (time.perf_counter() - t1) / args.steps
+        # (c) the render kernel's own time: the library's event pair around its launch (acr_stats.kernel_ms), no counting code in the kernel
+        own = []
+        for k in range(max(10, min(args.steps, 50))):
+            step(stats=3)
+            own.append(core.read_stats().kernel_ms)
+        kernel_ms = float(np.mean(own))
+        extra["kernel_ms_samples"] = len(own)
+        extra["kernel_ms_median"] = float(np.median(own))
+        # (d) the other mode, timed like the main region
+        if not cameras:
+            for _ in range(min(args.warmup, 5)):
+                step(mode_still=not still)
+            barrier()
+            t2 = time.perf_counter()
+            for k in range(args.steps):
+                step(mode_still=not still)
+            barrier()
+            extra["ms_per_step_moving" if still else "ms_per_step_still"] = 1e3 * (time.perf_counter() - t2) / args.steps
+        step_no[0] = last_timed
         # rays of the timed frames, counted afterwards so that the timed launches carry no instrumentation: the
         # same seeds and cameras back to back, the counters accumulating on the device, one read at the end
         for k in range(args.steps):
             if cameras:
                 core.set_camera(camera_of(first_timed + k))
-            core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=0, max_bounces=MAX_BOUNCES, screen_dev=ptr,
+            core.render(WIDTH, HEIGHT, seed=seed0 + first_timed + k, frames=first_timed + k if still else 0, max_bounces=MAX_BOUNCES, screen_dev=ptr,
                         collect_stats=1 if k == 0 else 2)
         st = core.read_stats()
         rays = st.rays_primary + st.rays_shadow + st.rays_bounce
         lds_bytes, lds_mode, interval, near_first, wave_tasks = st.lds_bytes, st.scene_in_lds, st.interval_traversal, st.near_first, st.wave_tasks
     else:
-        multi = run_multi(w, device, world, rank, args.steps, args.warmup, rehearsal, barrier)
+        multi = run_multi(w, device, world, rank, args.steps, args.warmup, rehearsal, barrier, still)
         elapsed, rays = multi["elapsed"], multi["rays"]
         if multi["same"] is False:
             raise SystemExit("assembled frame differs from the full-frame render")
@@ -319,18 +374,28 @@ def main():
                 if name == args.workload:
                     continue
                 rec = {"workload": WORKLOADS[name]["text"]}
+                tb = time.perf_counter()
+                # Building the scene (the 10 M-triangle soup most of all) is where one rank alone can fail, and it has no
+                # collective in it: the ranks agree on whether all of them got through before any enters run_multi,
+                # whose collectives a missing rank would leave the others waiting in.
+                w2, err = None, None
                 try:
-                    tb = time.perf_counter()
                     w2 = Workload(name, local_rank, args.block_order_every)
                     w2.core.set_stream(stream.cuda_stream)
+                except Exception as e:
+                    err = "%s: %s" % (type(e).__name__, e)
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if rehearsal else device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
                     k2 = 20
-                    m2 = run_multi(w2, device, world, rank, k2, 3, rehearsal, barrier)
+                    m2 = run_multi(w2, device, world, rank, k2, 3, rehearsal, barrier, still)
                     rec.update({"steps": k2, "ms_per_frame": 1e3 * m2["elapsed"] / k2, "Mrays_per_s": m2["rays"] / m2["elapsed"] / 1e6,
                                 "rays_per_frame": m2["rays"] / k2, "shares": m2["shares"], "assembled_equals_single_gpu": m2["same"],
                                 "setup_and_run_s": round(time.perf_counter() - tb, 1)})
+                else:
+                    rec["error"] = err or "another rank could not set this workload up"
+                if w2 is not None:
                     w2.close()
-                except Exception as e:  # the headline line must not be lost to a failure here
-                    rec["error"] = "%s: %s" % (type(e).__name__, e)
                 also.append(rec)
 
     # (several GPUs: run_multi has already taken the maximum of the ranks' times)
@@ -347,15 +412,19 @@ def main():
             "settle_frames": settle_frames if world == 1 else None,  # untimed frames before the warm-up that bring the GPU's clocks up from idle (--settle-ms)
             "ms_per_step": ms,
             "ms_per_frame": ms,
+            "mode": "still" if still else "moving",
+            **(extra if world == 1 else {}),
             "rays_per_frame": rays / args.steps,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": data_text,
-            "config": {"workload": wl["text"], "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
+            "config": {"workload": wl["text"] + (", camera still: frame k averaged in with frames = k" if still else ", frames=0 every step"), "width": WIDTH, "height": HEIGHT, "max_bounces": MAX_BOUNCES,
                        "parallelism": "single GPU, full frame" if world == 1 else
-                       f"full-width bands of {TILE_H} rows over {world} GPUs, contiguous runs balanced by measured cost and by each rank's measured speed (render + send), received in place on rank 0 over RCCL, two frames in flight"},
+                       (f"full-width bands of {TILE_H} rows over {world} GPUs, contiguous runs balanced by measured cost; every rank keeps the running mean of its own bands, "
+                                        "the pieces travel to GPU 0 over RCCL once, when the frame is read at the end of the timed region (inside it)" if still else
+                                        f"full-width bands of {TILE_H} rows over {world} GPUs, contiguous runs balanced by measured cost and by each rank's measured speed (render + send), received in place on rank 0 over RCCL, two frames in flight")},
         }
         if multi is not None:
             if multi["shares"] is not None:
@@ -372,7 +441,7 @@ def main():
             # and the kernel is bound by fp32 vector issue (divergence); with trees and triangles in HBM it is the
             # memory system.  `roofline` is the binding one, the other is reported beside it.
             roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": frame_bytes,
+                    "kernel": kernel, "kernel_ms": kernel_ms, "step_ms": extra["step_ms"], "algorithmic_bytes_per_launch": frame_bytes + (frame_bytes if still else 0),
                     "note": "LDS per workgroup %d B, staging mode %d (2 = whole scene resident in LDS, 1 = small tables only)" % (lds_bytes, lds_mode)}
             # HBM bytes per launch measured with rocprofv3 counter passes of this same command, when a summary is committed
             tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -449,7 +518,7 @@ def main():
                 tf = fl / rays0 * (rays / args.steps) / (kernel_ms * 1e-3) / 1e12
                 valu = {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_ray": fl / rays0,
-                        "kernel": kernel, "kernel_ms": kernel_ms,
+                        "kernel": kernel, "kernel_ms": kernel_ms, "step_ms": extra["step_ms"],
                         "frac_of_no_fma_ceiling": tf / (FP32_VECTOR_PEAK_TFLOPS / 2),
                         "frac_of_unpacked_no_fma_ceiling": tf / (FP32_VECTOR_PEAK_TFLOPS / 4),
                         "note": "peak counts an FMA as two flops and two packed operations per lane and cycle (v_pk_fma_f32); these "
@@ -461,7 +530,7 @@ def main():
                     # nodes and triangles are read from HBM: count them at the reference's record sizes
                     per_ray = (NODE_BYTES * counters["node_visits"] + TRIANGLE_BYTES * counters["triangle_tests"]) / rays0
                     roof["algorithmic_bytes_per_ray"] = per_ray
-                    roof["algorithmic_bytes_per_launch"] = frame_bytes + per_ray * rays / args.steps
+                    roof["algorithmic_bytes_per_launch"] += per_ray * rays / args.steps
                 # parity: GPU vs oracle on the sampled rows, every pixel
                 core.resize(WIDTH, HEIGHT)
                 core.render(WIDTH, HEIGHT, seed=seed0, frames=0, max_bounces=MAX_BOUNCES)

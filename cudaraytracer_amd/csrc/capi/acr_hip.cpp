@@ -12,7 +12,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -42,6 +44,7 @@ static __device__ __align__(256) unsigned char scratch[sizeof(StaticScratch)];
 struct acr_hip_ctx
 {
 	int device = 0;
+	uint32_t xcds = 0; // XCDs of the device (hipDeviceAttributeNumberOfXccs, or the environment's ACR_XCDS); 0: unknown
 	StaticScratch *staticScratch = nullptr; // this device's copy of `scratch`
 	hipStream_t ownStream = nullptr;
 	hipStream_t stream = nullptr;
@@ -141,6 +144,7 @@ struct acr_hip_ctx
 	size_t sortCap = 0;
 	hipEvent_t evStart = nullptr, evStop = nullptr;
 	bool timed = false;
+	bool counted = false; // the last render also counted its rays (ACR_STATS_FRAME / ACR_STATS_ACCUMULATE)
 	acr_stats stats{};
 	size_t lastSlots = 0; // pixel slots written by the last render
 	bool statsStatic = false; // the last render was acr_hip_render_static: its list counter is scratch's
@@ -408,6 +412,11 @@ int acr_hip_create(int device_ordinal, acr_hip_ctx **out)
 		return ACR_ERR_HIP;
 	}
 	ctx->staticScratch = static_cast<StaticScratch *>(sp);
+	// The XCD-aware block order assumes that workgroup i of a launch runs on XCD i % 8 (an unpartitioned MI300 / MI355
+	// class device): anything else keeps the plain order by cost.
+	int xccs = 0;
+	if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device_ordinal) == hipSuccess && xccs > 0) ctx->xcds = uint32_t(xccs);
+	if (const char *env = getenv("ACR_XCDS")) ctx->xcds = uint32_t(strtoul(env, nullptr, 10));
 	*out = ctx;
 	return ACR_OK;
 }
@@ -513,9 +522,40 @@ int acr_hip_selftest_reciprocal(acr_hip_ctx *ctx, uint64_t *mismatches)
 	return ACR_OK;
 }
 
+// The kernels' reciprocal shortcut (acr::math::reciprocalNewton) is the division's result on gfx950; whether it also is
+// on the GPU at hand is checked once per device and process, before the first scene is uploaded to it.
+static int checkReciprocalOnce(acr_hip_ctx *ctx)
+{
+#ifdef ACR_NO_RCP
+	(void)ctx;
+	return ACR_OK; // built with divisions throughout: nothing to check
+#else
+	static std::mutex lock;
+	static int verdict[64] = {}; // per device: 0 not run, 1 good, 2 bad
+	const int d = ctx->device;
+	if (d < 0 || d >= 64) return ACR_OK;
+	std::lock_guard<std::mutex> g(lock);
+	if (verdict[d] == 0) {
+		if (const char *env = getenv("ACR_SKIP_RCP_SELFTEST"); env && env[0] == '1') {
+			verdict[d] = 1;
+		} else {
+			uint64_t bad = 0;
+			const int rc = acr_hip_selftest_reciprocal(ctx, &bad);
+			if (rc != ACR_OK) return rc;
+			verdict[d] = bad == 0 ? 1 : 2;
+		}
+	}
+	if (verdict[d] == 2)
+		return fail(ctx, ACR_ERR_UNSUPPORTED, "this GPU's reciprocal approximation plus one Newton step is not the correctly rounded 1 / x the kernels "
+		            "were verified with (acr_hip_selftest_reciprocal): rebuild the library with -DACR_NO_RCP");
+	return ACR_OK;
+#endif
+}
+
 int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 {
 	if (!ctx || !s) return fail(ctx, ACR_ERR_INVALID, "null argument");
+	if (const int rc = checkReciprocalOnce(ctx); rc != ACR_OK) return rc;
 	std::string why;
 	if (s->num_objects >= (1u << 28) || s->num_triangles >= (1u << 28) || s->num_mesh_nodes >= (1u << 28))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "scene too large for 28-bit item indices");
@@ -968,7 +1008,8 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	p.screen = ownBuffers ? ctx->screen : static_cast<float4 *>(screen_dev);
 	p.primid = primid_dev ? primid_dev : (ownBuffers ? ctx->primid : nullptr);
 	p.hit_t = hit_t_dev ? hit_t_dev : (ownBuffers ? ctx->hitT : nullptr);
-	p.counters = f->collect_stats ? ctx->counters : nullptr;
+	const bool countRays = f->collect_stats == ACR_STATS_FRAME || f->collect_stats == ACR_STATS_ACCUMULATE;
+	p.counters = countRays ? ctx->counters : nullptr;
 	p.tile_rays = f->tile_rays_dev;
 	p.tile_cycles = f->tile_cycles_dev;
 	if (p.tile_rays) ACR_HIP_TRY(ctx, hipMemsetAsync(p.tile_rays, 0, sizeof(uint32_t) * f->num_tiles, ctx->stream));
@@ -1035,8 +1076,9 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	}
 
 	ctx->timed = f->collect_stats != 0;
+	ctx->counted = countRays;
 	if (ctx->timed) {
-		if (f->collect_stats != ACR_STATS_ACCUMULATE)
+		if (f->collect_stats == ACR_STATS_FRAME)
 			ACR_HIP_TRY(ctx, hipMemsetAsync(ctx->counters, 0, kCounterSlots * 4 * sizeof(unsigned long long), ctx->stream));
 		ACR_HIP_TRY(ctx, hipEventRecord(ctx->evStart, ctx->stream));
 	}
@@ -1069,7 +1111,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 			// A list of full-width bands of 16 rows (the multi-GPU split) numbers its blocks row by row like a frame
 			// of its own; other tile lists keep the plain order.
 			const uint32_t bx = !tiled ? (f->width + 15) / 16 : ((f->tile_h == 16 && f->tile_w >= f->width) ? f->tile_w >> 4 : 0u);
-			if (bx != 0 && plan.ldsMode != 2) {
+			if (bx != 0 && plan.ldsMode != 2 && ctx->xcds == acr::dev::kXcdsAssumed) {
 				if (ctx->blockZCount != numBlocks || ctx->blockZBlocksX != bx) {
 					auto spread = [](uint32_t v) { // bit k of v to bit 2k
 						uint64_t r = 0;
@@ -1205,15 +1247,17 @@ int acr_hip_read_stats(acr_hip_ctx *ctx, acr_stats *stats)
 	ACR_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ACR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timed) {
-		static_assert(kCounterSlots * 4 * sizeof(unsigned long long) <= 65536, "read into a stack buffer");
-		unsigned long long slots[kCounterSlots * 4];
-		ACR_HIP_TRY(ctx, hipMemcpy(slots, ctx->counters, sizeof(slots), hipMemcpyDeviceToHost));
-		unsigned long long c[4] = {0, 0, 0, 0};
-		for (uint32_t k = 0; k < kCounterSlots * 4; k++) c[k & 3] += slots[k];
-		ctx->stats.rays_primary = c[0];
-		ctx->stats.rays_shadow = c[1];
-		ctx->stats.rays_bounce = c[2];
-		ctx->stats.primary_hits = c[3];
+		if (ctx->counted) {
+			static_assert(kCounterSlots * 4 * sizeof(unsigned long long) <= 65536, "read into a stack buffer");
+			unsigned long long slots[kCounterSlots * 4];
+			ACR_HIP_TRY(ctx, hipMemcpy(slots, ctx->counters, sizeof(slots), hipMemcpyDeviceToHost));
+			unsigned long long c[4] = {0, 0, 0, 0};
+			for (uint32_t k = 0; k < kCounterSlots * 4; k++) c[k & 3] += slots[k];
+			ctx->stats.rays_primary = c[0];
+			ctx->stats.rays_shadow = c[1];
+			ctx->stats.rays_bounce = c[2];
+			ctx->stats.primary_hits = c[3];
+		}
 		float ms = 0;
 		ACR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
 		ctx->stats.kernel_ms = ms;
@@ -1243,7 +1287,13 @@ int32_t *acr_hip_path_votes(acr_hip_ctx *ctx)
 			fail(ctx, ACR_ERR_HIP, "no memory for %zu bytes of path votes", bytes);
 			return nullptr;
 		}
-		if (hipMemsetAsync(ctx->pathVotes, 0, bytes, ctx->stream) != hipSuccess) return nullptr;
+		if (hipMemsetAsync(ctx->pathVotes, 0, bytes, ctx->stream) != hipSuccess) {
+			// the header promises a zeroed table: a retry must allocate and zero again, not find this one
+			(void)hipFree(ctx->pathVotes);
+			ctx->pathVotes = nullptr;
+			fail(ctx, ACR_ERR_HIP, "could not zero %zu bytes of path votes", bytes);
+			return nullptr;
+		}
 	}
 	return ctx->pathVotes;
 }

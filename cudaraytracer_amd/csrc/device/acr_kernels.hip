@@ -2180,7 +2180,7 @@ __global__ void __launch_bounds__(kOrderThreads) orderBlocksKernel(uint32_t *__r
 // neighbouring parts of the trees at the same time.  A run with more blocks than its XCD has positions (cheap
 // blocks) hands its cheapest ones to the positions that the runs with few, expensive blocks leave free at their
 // XCDs' ends.  One workgroup; thread t owns a stretch of the Z-curve.  Leaves cost[] at zero like orderBlocksKernel.
-constexpr uint32_t kXcds = 8;
+constexpr uint32_t kXcds = kXcdsAssumed;
 __global__ void __launch_bounds__(kOrderThreads) orderBlocksRegionsKernel(uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order,
                                                                           const uint32_t *__restrict__ zseq)
 {

@@ -84,6 +84,9 @@ namespace dev
 	constexpr uint32_t kWaveMaxTriangles = 1u << kTaskTriBits, kWaveMaxMaterials = 1u << (18u - kTaskTriBits);
 	constexpr uint32_t waveLdsWords() { return 2u * kWaveCap; }
 
+	// XCDs the XCD-aware block order is written for (workgroup i of a launch on XCD i % 8)
+	constexpr uint32_t kXcdsAssumed = 8;
+
 	// workgroups of the list pass
 	constexpr uint32_t kRedoGrid = 64;
 

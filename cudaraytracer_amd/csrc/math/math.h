@@ -64,11 +64,16 @@ namespace math
 	// number (zero, denormal, infinite, NaN).  Neither statement is an estimate: all 2^32 argument patterns have
 	// been compared on gfx950, and acr_hip_selftest_reciprocal repeats that on the GPU at hand (part of the GPU
 	// tests).  Hence: a normal result IS the quotient; anything else is computed again by the division.
+	// Built with -DACR_NO_RCP the shortcut is the division itself (for a GPU on which the self-test fails).
 #if defined(__HIPCC__)
 	__device__ inline float reciprocalNewton(float x)
 	{
+#ifdef ACR_NO_RCP
+		return 1.0f / x;
+#else
 		const float r = __builtin_amdgcn_rcpf(x);
 		return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#endif
 	}
 #endif
 	ACR_HD float reciprocal(float x)

@@ -24,6 +24,9 @@ CPU ranks in tests:
         out      : torch tensor [len(tile_ids), tile_h * tile_w, 4] float32 to fill
         cost     : torch tensor [len(tile_ids)] int32 to fill (any positive cost measure), or None when
                    this frame's costs are not needed
+    With accumulate=True the call carries a fourth, keyword argument, frames=k: the number of frames already
+    averaged into `out`, which then holds the running mean of those frames on entry (k == 0: overwrite) and
+    of one more frame on return (renderer.cu:375-387).
 """
 import ctypes as C
 
@@ -175,14 +178,20 @@ class DistributedRenderer:
     Per-tile costs live in one [num_tiles] vector in visiting order."""
 
     def __init__(self, width, height, render_tiles, device, tile_w=None, tile_h=16, scatter=None, rebalance_every=1,
-                 stage_through_host=False, depth=2):
+                 stage_through_host=False, depth=2, accumulate=False):
         """scatter(tiles, tile_ids, frame): writes compact tiles into the full frame tensor
         [height, width, 4] on rank 0; None selects a torch implementation (tiles layout only).
         rebalance_every: the assignment is rebuilt from the measured costs every this many frames (0 = never);
         the reference re-sorts its pixel table every 60 still frames (renderer.cu:392,457).
         stage_through_host: move tiles and costs through CPU tensors for the exchange (for a process group
         whose backend cannot carry device tensors, e.g. gloo when rehearsing the multi-rank path on one GPU).
-        depth: frame buffers in flight (bands layout)."""
+        depth: frame buffers in flight (bands layout).
+        accumulate: progressive accumulation while the camera stands still, the reference's render loop
+        (renderer.cu:375-387,423): frame k is averaged into the running mean of the frames before it.  Bands layout
+        only.  Every rank keeps the running mean of the bands it owns, in one frame buffer; nothing is exchanged
+        per frame; finish() gathers the pieces on rank 0 (only then, or every `gather_every` frames if that
+        attribute is set); when a rebalance moves bands to another rank their running means travel from the old
+        owner to the new one; camera_moved() restarts the mean (the next frame overwrites, as frames == 0 does)."""
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.device = device
@@ -197,7 +206,14 @@ class DistributedRenderer:
         self.width, self.height = width, height
         n = self.plan.num_tiles
         self.bands = self.plan.bands
-        self.depth = max(1, depth) if self.bands else 1
+        self.accumulate = bool(accumulate)
+        if self.accumulate and not self.bands:
+            raise ValueError("accumulation across ranks needs the bands layout (a width that is a multiple of 16, tile_w == width)")
+        self.depth = (1 if self.accumulate else max(1, depth)) if self.bands else 1
+        self.still_frames = 0       # accumulate: frames averaged into the running means so far
+        self.gather_every = 0       # accumulate: also gather on rank 0 every this many frames (0: only in finish())
+        self._gathered_at = -1      # frame_no whose pieces rank 0 holds
+        self._owned = None          # accumulate: the split (begin offsets) the running means are distributed by
         # bands: every rank renders into frame-shaped buffers (rank 0's are the assembled frames);
         # tiles: rank 0 holds every tile, the others their own run (sized for the largest possible run)
         self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=device)
@@ -233,6 +249,8 @@ class DistributedRenderer:
         self.frames_since_rebalance = 0
         self._drop_cost_updates()
         self.plan.reset()
+        self.still_frames = 0  # the next frame overwrites: no running mean needs to follow the new split
+        self._owned = None
 
     def _drop_cost_updates(self):
         for _, _, ready in self._cost_updates:
@@ -252,7 +270,11 @@ class DistributedRenderer:
             p.update(by_tile)
 
     def finish(self):
-        """Waits for every exchange still in flight; returns the most recent frame on rank 0."""
+        """Waits for every exchange still in flight; returns the most recent frame on rank 0.  With accumulation
+        this is where the ranks' pieces travel to rank 0, unless they already have for this frame."""
+        if self.accumulate and self.world > 1 and self.frame_no and self._gathered_at != self.frame_no:
+            self._exchange(0)
+            self._gathered_at = self.frame_no
         for slot in range(self.depth):
             for w in self.pending[slot]:
                 w.wait()
@@ -281,13 +303,13 @@ class DistributedRenderer:
     def _exchange(self, slot):
         """Bands layout: posts the point-to-point exchange of the frame in buffer `slot` (rank 0 receives every
         other rank's piece in place, the others send theirs); the handles go to self.pending[slot]."""
-        p = self.plan
+        begin = self._owned if (self.accumulate and self._owned is not None) else self.plan.begin
         flat = self.frames[slot].view(-1, 4)
-        px0, px1 = self._band_pixels(int(p.begin[self.rank]), int(p.begin[self.rank + 1]))
+        px0, px1 = self._band_pixels(int(begin[self.rank]), int(begin[self.rank + 1]))
         ops, staged = [], {}
         if self.rank == 0:
             for r in range(1, self.world):
-                q0, q1 = self._band_pixels(int(p.begin[r]), int(p.begin[r + 1]))
+                q0, q1 = self._band_pixels(int(begin[r]), int(begin[r + 1]))
                 if q1 > q0:
                     dst = flat[q0:q1]
                     if self.stage_through_host:
@@ -306,6 +328,36 @@ class DistributedRenderer:
                 dst.copy_(buf)
         self.pending[slot] = works
 
+    def _move_running_means(self, old, new):
+        """accumulate: the split changed from `old` to `new` (begin offsets) while running means exist: the bands
+        that change owner travel from the old owner's frame buffer to the new owner's, point to point."""
+        flat = self.frames[0].view(-1, 4)
+        ops, staged = [], []
+        for i in range(self.world):          # old owner
+            for j in range(self.world):      # new owner
+                if i == j or self.rank not in (i, j):
+                    continue
+                b0, b1 = max(int(old[i]), int(new[j])), min(int(old[i + 1]), int(new[j + 1]))
+                if b1 <= b0:
+                    continue
+                q0, q1 = self._band_pixels(b0, b1)
+                if q1 <= q0:
+                    continue
+                piece = flat[q0:q1]
+                if self.rank == i:
+                    ops.append(dist.P2POp(dist.isend, piece.cpu() if self.stage_through_host else piece, j))
+                else:
+                    dst = piece
+                    if self.stage_through_host:
+                        dst = torch.empty(piece.shape, dtype=piece.dtype)
+                        staged.append((dst, piece))
+                    ops.append(dist.P2POp(dist.irecv, dst, i))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf, dst in staged:
+            dst.copy_(buf)
+
     def calibrate(self, frames=3):
         """Measures how fast each rank gets its share done and sets the ranks' shares accordingly.
 
@@ -316,8 +368,8 @@ class DistributedRenderer:
         with one all-reduce, and solve_shares() turns them into shares (call it two or three times: from the
         second call on it has two measurements at different shares and can tell each phase's fixed cost from its
         cost per band).  Bands layout only; a no-op for one rank.  The frames rendered here are ordinary frames."""
-        if self.world == 1 or not self.bands:
-            return None
+        if self.world == 1 or not self.bands or self.accumulate:
+            return None  # (with accumulation nothing is sent per frame: the ranks' shares stay equal)
         import time
         on_gpu = torch.device(self.device).type == "cuda"
 
@@ -379,7 +431,19 @@ class DistributedRenderer:
             w.wait()
         self.pending[slot] = []
 
-        if self.bands:
+        if self.bands and self.accumulate:
+            if self.still_frames > 0 and self._owned is not None and self.world > 1 and list(self._owned) != list(p.begin):
+                self._move_running_means(self._owned, p.begin)
+            self._owned = np.array(p.begin, copy=True)
+            flat = self.frames[0].view(-1, 4)
+            px0, px1 = self._band_pixels(b0, b1)
+            self.render_tiles(p.order[b0:b1], flat[px0:px1], cost, frames=self.still_frames)
+            self.still_frames += 1
+            self._last_slot = 0
+            if self.world > 1 and self.gather_every and self.still_frames % self.gather_every == 0:
+                self._exchange(0)
+                self._gathered_at = self.frame_no + 1
+        elif self.bands:
             flat = self.frames[slot].view(-1, 4)
             px0, px1 = self._band_pixels(b0, b1)
             out = flat[px0:px1]
@@ -450,13 +514,15 @@ def hip_render_tiles(core, width, height, tile_w, tile_h, frame_args, cost_kind=
     the C ABI.  The per-tile cost is `fn.cost_kind` (an attribute the caller may change between frames):
     "cycles", the wave clock ticks spent in the tile -- what balancing wants, since a ray through the floor of the
     Cornell box costs ten times one to its ceiling -- or "rays", the number of rays traced, for counting."""
-    def fn(tile_ids, out, cost):
+    def fn(tile_ids, out, cost, frames=None):
         args = frame_args() if callable(frame_args) else dict(frame_args)
-        if args.get("frames", 0) != 0:
+        if frames is not None:
+            args["frames"] = frames  # DistributedRenderer(accumulate=True): `out` holds the running mean of that many frames
+        elif args.get("frames", 0) != 0:
             # the running mean reads the pixel's previous value (renderer.cu:375-387): with frame buffers in
             # rotation and bands that change owner between frames that value is another frame's, or another rank's
-            raise ValueError("rendering across GPUs takes frames == 0 only (every frame overwrites, as after a camera move); "
-                             "accumulate on one GPU, or average the assembled frames on rank 0")
+            raise ValueError("frames > 0 across GPUs needs DistributedRenderer(accumulate=True), which keeps every band's running mean "
+                             "with its owner; without it every frame renders with frames == 0 (as after a camera move)")
         if len(tile_ids) == 0:
             return  # nothing of this frame is this rank's (an empty list would mean "the whole frame" to the C ABI)
         ptr = None if cost is None else C.c_void_p(cost.data_ptr())

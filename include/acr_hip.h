@@ -175,6 +175,7 @@ typedef struct acr_frame {
 #define ACR_STATS_OFF        0
 #define ACR_STATS_FRAME      1  /* counters of this launch alone */
 #define ACR_STATS_ACCUMULATE 2  /* counters keep what earlier launches added: totals of a run of frames with one read at its end */
+#define ACR_STATS_TIME       3  /* only the HIP-event time of the launch (acr_stats::kernel_ms): the kernel carries no counting code */
 
 typedef struct acr_stats {
 	uint64_t rays_primary, rays_shadow, rays_bounce;   /* rays actually traced by the last render */

@@ -151,6 +151,114 @@ def test_frame_assembly_across_ranks(tmp_path, world, layout):
         assert ws[0] == 0 and ws[-1] == n and (ws[2] - ws[1]) == min(np.diff(ws)) and (ws[2] - ws[1]) < (ws[1] - ws[0])   # the slow rank renders the fewest bands
 
 
+def _accumulate_worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cudaraytracer_amd as acr
+    import oracle
+    from cudaraytracer_amd import distributed as D
+
+    data = acr.ImportData.load(os.path.join(HERE, "golden", "scenes", "cornell-box-cycles.json"))
+    view, keep = data.pack()
+    o = oracle.OracleScene(view)
+    state = dict(seed=0)
+    calls = []
+
+    def render_bands(tile_ids, out, cost, frames):
+        # stand-in for the GPU core: the oracle averages frame `frames` into the rows of this rank's bands, whose
+        # running mean `out` holds (renderer.cu:375-387)
+        calls.append((len(tile_ids), frames))
+        if len(tile_ids) == 0:
+            return
+        assert list(tile_ids) == list(range(int(tile_ids[0]), int(tile_ids[0]) + len(tile_ids)))
+        r0, r1 = int(tile_ids[0]) * TH, min((int(tile_ids[-1]) + 1) * TH, H)
+        screen = np.zeros((H, W, 4), np.float32)
+        screen[r0:r1] = out.numpy().reshape(r1 - r0, W, 4)
+        r = o.render(W, H, seed=state["seed"], frames=frames, max_bounces=2, threads=2, screen=screen, row_begin=r0, row_end=r1)
+        out.copy_(torch.from_numpy(r["screen"][r0:r1].reshape(-1, 4)))
+        if cost is not None:
+            c = [1 + int((r["prim"][b * TH:min((b + 1) * TH, H)] != 0xFFFFFFFF).sum()) for b in tile_ids]
+            cost.copy_(torch.tensor(c, dtype=torch.int32))
+
+    dr = D.DistributedRenderer(W, H, render_bands, torch.device("cpu"), tile_w=W, tile_h=TH, rebalance_every=2, accumulate=True)
+    assert dr.bands and dr.depth == 1
+    results = {}
+
+    def reference(seeds):
+        screen = None
+        for f, seed in enumerate(seeds):
+            screen = o.render(W, H, seed=seed, frames=f, max_bounces=2, threads=2, screen=screen)["screen"]
+        return screen
+
+    # frames 0..5 with the camera still; the costs measured on frames 1 and 3 rebuild the split one frame later, so
+    # running means change owner in the middle of the accumulation
+    seeds = [100 + f for f in range(6)]
+    splits = []
+    for seed in seeds:
+        state["seed"] = seed
+        dr.render_frame()
+        splits.append(dr.last_split)
+    frame = dr.finish()
+    if rank == 0:
+        results["equal_still"] = bool(np.array_equal(frame.numpy().view(np.uint32), reference(seeds).view(np.uint32)))
+    every = [None] * world
+    dist.all_gather_object(every, splits)
+    assert all(e == every[0] for e in every)
+    # a second read without a new frame exchanges nothing more and returns the same frame
+    again = dr.finish()
+    if rank == 0:
+        results["equal_again"] = bool(np.array_equal(again.numpy().view(np.uint32), frame.numpy().view(np.uint32)))
+    # two more frames on top (the gather wrote into rank 0's copy of the others' bands, never into anyone's own bands)
+    for seed in (106, 107):
+        state["seed"] = seed
+        dr.render_frame()
+    frame = dr.finish()
+    if rank == 0:
+        results["equal_eight"] = bool(np.array_equal(frame.numpy().view(np.uint32), reference(seeds + [106, 107]).view(np.uint32)))
+    # the camera moves: the mean restarts, the split is uniform again
+    dr.camera_moved()
+    dr.gather_every = 1
+    exchanges = []
+    plain_exchange = dr._exchange
+    dr._exchange = lambda slot: (exchanges.append(dr.frame_no), plain_exchange(slot))
+    for seed in (200, 201, 202):
+        state["seed"] = seed
+        dr.render_frame()
+        splits.append(dr.last_split)
+    frame = dr.finish()
+    # gather_every = 1: the pieces travelled after every frame, and finish() had nothing left to exchange
+    assert len(exchanges) == 3
+    if rank == 0:
+        results["equal_moved"] = bool(np.array_equal(frame.numpy().view(np.uint32), reference([200, 201, 202]).view(np.uint32)))
+    if rank == 0:
+        results["splits"] = splits
+        results["frames_passed"] = [c[1] for c in calls]
+        torch.save(results, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_progressive_accumulation_across_ranks(tmp_path, world):
+    """frames > 0 across ranks: every rank keeps the running mean of its bands, a rebalance in the middle moves
+    running means between ranks, the gather happens when the frame is read; bit-identical to one process
+    accumulating the same frames"""
+    out = str(tmp_path / "res.pt")
+    mp.start_processes(_accumulate_worker, args=(world, _free_port(), out), nprocs=world, join=True, start_method="spawn")
+    res = torch.load(out)
+    assert res["equal_still"] and res["equal_again"] and res["equal_eight"] and res["equal_moved"]
+    splits = res["splits"]
+    uniform = splits[0]
+    assert splits[1] == uniform
+    assert any(s != uniform for s in splits[2:6])   # bands changed owner while frames were being averaged
+    assert splits[6] == uniform                     # uniform again after the camera move (frames 106, 107 are not in the list)
+    assert res["frames_passed"] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2]
+
+
 def test_single_rank_path_without_process_group():
     """world size 1: no communication at all, same assembly code."""
     sys.path.insert(0, HERE)

@@ -66,6 +66,40 @@ def test_render_static_equals_render(acr, built):
         other.close()
 
 
+def test_render_static_allocates_nothing(acr, built):
+    """The property the entry point exists for: a warmed context's static calls leave the device's free memory
+    where it was -- frames of new sizes, new bounce counts and a scene switch included (each of which makes the
+    allocating entry point grow or create a buffer; shown on a second context as the control)."""
+    import torch
+    b = built["cornell-box-cycles"]
+    core = acr.HipCore(0)
+    other = acr.HipCore(0)
+    screen = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    ptr = C.c_void_p(screen.data_ptr())
+    try:
+        for c in (core, other):
+            c.upload_scene(b.scene.soa)
+            c.set_camera(b.scene.camera)
+        core.render(64, 64, seed=1, max_bounces=1, static=True, screen_dev=ptr)  # loads the kernels' code objects
+        core.render(64, 64, seed=1, max_bounces=3, static=True, screen_dev=ptr)
+        core.sync()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for k, (w, h, bounces) in enumerate([(1920, 1080, 1), (640, 360, 4), (1280, 720, 2), (33, 17, 5)]):
+            core.render(w, h, seed=20 + k, frames=0, max_bounces=bounces, static=True, screen_dev=ptr)
+            core.render(w, h, seed=30 + k, frames=1, max_bounces=bounces, static=True, screen_dev=ptr)
+        core.sync()
+        assert torch.cuda.mem_get_info(0)[0] == free0, "acr_hip_render_static changed the device's free memory"
+        # control: the allocating entry point does take memory for the same frames (its list of pixel slots)
+        other.render(1920, 1080, seed=20, frames=0, max_bounces=1, screen_dev=ptr)
+        other.sync()
+        assert torch.cuda.mem_get_info(0)[0] < free0
+    finally:
+        core.close()
+        other.close()
+        del screen
+
+
 def test_render_static_refuses_what_would_allocate(acr, orc, built):
     from conftest import Built, soup_data
     b = built["cornell-box-cycles"]
