@@ -336,6 +336,10 @@ def main():
         # (c) the render kernel's own time: the library's event pair around its launch (acr_stats.kernel_ms), no counting code in the kernel
         own = []
         for k in range(max(10, min(args.steps, 50))):
+            # each sample is the last of ten launches queued back to back: reading the events waits for the stream, and a
+            # kernel launched onto an idle GPU is not the kernel of a running renderer
+            for _ in range(9):
+                step()
             step(stats=3)
             own.append(core.read_stats().kernel_ms)
         kernel_ms = float(np.mean(own))
@@ -343,7 +347,7 @@ def main():
         extra["kernel_ms_median"] = float(np.median(own))
         # (d) the other mode, timed like the main region
         if not cameras:
-            for _ in range(min(args.warmup, 5)):
+            for _ in range(max(args.warmup, 40)):  # the passes above waited for the stream after every frame
                 step(mode_still=not still)
             barrier()
             t2 = time.perf_counter()

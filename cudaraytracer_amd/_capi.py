@@ -89,7 +89,7 @@ class Frame(C.Structure):
                 ("max_bounces", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
                 ("num_tiles", C.c_uint32), ("tile_ids", c_u32_p), ("pixel_values_dev", C.c_void_p),
                 ("collect_stats", C.c_uint32), ("tile_rays_dev", C.c_void_p), ("tile_cycles_dev", C.c_void_p),
-                ("path_keys_dev", C.c_void_p), ("block_order_dev", C.c_void_p)]
+                ("path_keys_dev", C.c_void_p), ("block_order_dev", C.c_void_p), ("tiles_into_frame", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -131,6 +131,22 @@ HIP_SYMBOLS = {
     "acr_hip_sort_pixel_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "acr_hip_scatter_tiles": (C.c_int, [C.c_void_p, C.c_void_p, c_u32_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32, C.c_void_p]),
+    "acr_hip_group_create": (C.c_int, [C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "acr_hip_group_destroy": (None, [C.c_void_p]),
+    "acr_hip_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "acr_hip_group_size": (C.c_uint32, [C.c_void_p]),
+    "acr_hip_group_context": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "acr_hip_group_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneSoA)]),
+    "acr_hip_group_set_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
+    "acr_hip_group_get_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),
+    "acr_hip_group_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "acr_hip_group_set_balance": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p]),
+    "acr_hip_group_split": (C.c_int, [C.c_void_p, c_u32_p, c_u32_p]),
+    "acr_hip_group_render": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int]),
+    "acr_hip_group_frame": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "acr_hip_group_read_framebuffer": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "acr_hip_group_read_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "acr_hip_group_sync": (C.c_int, [C.c_void_p]),
 }
 
 HOST_SYMBOLS = {
@@ -148,6 +164,7 @@ HOST_SYMBOLS = {
     "acr_host_scene_bih_text": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
     "acr_host_scene_bih_defined": (C.c_int, [C.c_void_p, C.c_uint32, c_u8_p, C.c_uint32]),
     "acr_host_renderer_create": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]),
+    "acr_host_renderer_create_multi": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
     "acr_host_renderer_destroy": (None, [C.c_void_p]),
     "acr_host_renderer_error": (C.c_char_p, [C.c_void_p]),
     "acr_host_renderer_load_scene": (C.c_int, [C.c_void_p, C.c_void_p]),

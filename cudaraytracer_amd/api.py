@@ -168,7 +168,8 @@ class HipCore:
 
     def render(self, width, height, seed=0, frames=0, max_bounces=1, collect_stats=False, screen_dev=None,
                primid_dev=None, hit_t_dev=None, tile_ids=None, tile_w=0, tile_h=0, pixel_values_dev=None,
-               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None, static=False):
+               tile_rays_dev=None, tile_cycles_dev=None, path_keys_dev=None, block_order_dev=None, static=False,
+               tiles_into_frame=False):
         """acr_hip_render; static=True calls acr_hip_render_static, the variant that allocates nothing."""
         f = _capi.Frame()
         f.width, f.height, f.seed, f.frames, f.max_bounces = width, height, seed, frames, max_bounces
@@ -183,6 +184,7 @@ class HipCore:
         f.tile_cycles_dev = tile_cycles_dev
         f.path_keys_dev = path_keys_dev
         f.block_order_dev = block_order_dev
+        f.tiles_into_frame = 1 if tiles_into_frame else 0
         if static:
             self._check(self._lib.acr_hip_render_static(self._h, C.byref(f), screen_dev, primid_dev, hit_t_dev), "acr_hip_render_static")
         else:
@@ -253,13 +255,104 @@ class HipCore:
                                                     tile_w, tile_h, width, height, frame_dev), "acr_hip_scatter_tiles")
 
 
+class HipGroup:
+    """acr_hip_group (include/acr_hip.h): one frame across several GPUs from one host thread.  devices: GPU
+    ordinals, one per member (a GPU may be named more than once); frames are assembled on the first one."""
+
+    def __init__(self, devices):
+        self._lib = _capi.hip_lib()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._lib.acr_hip_group_create(len(devices), devs, C.byref(h))
+        if rc != 0 or not h:
+            raise RuntimeError(f"acr_hip_group_create(devices={list(devices)}) failed with code {rc}: no usable GPU")
+        self._h = h
+        self.size = len(devices)
+        self._w = self._hh = 0
+
+    def close(self):
+        if self._h:
+            self._lib.acr_hip_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.acr_hip_group_last_error(self._h).decode()}")
+
+    def upload_scene(self, soa):
+        self._check(self._lib.acr_hip_group_upload_scene(self._h, C.byref(soa)), "acr_hip_group_upload_scene")
+
+    def set_camera(self, cam):
+        self._check(self._lib.acr_hip_group_set_camera(self._h, C.byref(cam)), "acr_hip_group_set_camera")
+
+    def resize(self, w, h):
+        self._check(self._lib.acr_hip_group_resize(self._h, w, h), "acr_hip_group_resize")
+        self._w, self._hh = w, h
+
+    def set_balance(self, rebalance_every=16, weights=None):
+        wp = None
+        if weights is not None:
+            weights = np.ascontiguousarray(weights, dtype=np.float32)
+            if len(weights) != self.size:
+                raise ValueError("one weight per member")
+            wp = weights.ctypes.data_as(_capi.c_float_p)
+        self._check(self._lib.acr_hip_group_set_balance(self._h, rebalance_every, wp), "acr_hip_group_set_balance")
+
+    def split(self):
+        """begin offsets: member i renders bands [begin[i], begin[i + 1]) of the next frame"""
+        begin = np.zeros(self.size + 1, dtype=np.uint32)
+        n = C.c_uint32()
+        self._check(self._lib.acr_hip_group_split(self._h, begin.ctypes.data_as(_capi.c_u32_p), C.byref(n)), "acr_hip_group_split")
+        return [int(x) for x in begin], int(n.value)
+
+    def member_set_traversal(self, i, mode):
+        ctx = self._lib.acr_hip_group_context(self._h, i)
+        if self._lib.acr_hip_set_traversal(ctx, mode) != 0:
+            raise RuntimeError("acr_hip_set_traversal failed")
+
+    def render(self, seed=0, frames=0, max_bounces=1, collect_stats=0, gather=False):
+        f = _capi.Frame()
+        f.width, f.height, f.seed, f.frames, f.max_bounces = self._w, self._hh, seed, frames, max_bounces
+        f.collect_stats = int(collect_stats)
+        self._check(self._lib.acr_hip_group_render(self._h, C.byref(f), 1 if gather else 0), "acr_hip_group_render")
+
+    def frame_ptr(self):
+        p = C.c_void_p()
+        self._check(self._lib.acr_hip_group_frame(self._h, C.byref(p)), "acr_hip_group_frame")
+        return p.value
+
+    def read_framebuffer(self):
+        out = np.zeros((self._hh, self._w, 4), dtype=np.float32)
+        self._check(self._lib.acr_hip_group_read_framebuffer(self._h, out.ctypes.data_as(_capi.c_float_p), out.size), "acr_hip_group_read_framebuffer")
+        return out
+
+    def read_stats(self):
+        s = _capi.Stats()
+        self._check(self._lib.acr_hip_group_read_stats(self._h, C.byref(s)), "acr_hip_group_read_stats")
+        return s
+
+    def sync(self):
+        self._check(self._lib.acr_hip_group_sync(self._h), "acr_hip_group_sync")
+
+
 class Renderer:
     """acr::Renderer without the window: Renderer(Args{dim}), loadScene, render, moveCamera."""
 
-    def __init__(self, width, height, samples=1, device=0):
+    def __init__(self, width, height, samples=1, device=0, devices=None, rebalance_every=16):
+        """devices: a list of GPU ordinals renders every frame across them (Renderer::Args::devices)"""
         self._lib = _capi.host_lib()
         err = _err_buf()
-        self._h = self._lib.acr_host_renderer_create(width, height, samples, device, err, len(err))
+        if devices is not None and len(devices) > 1:
+            devs = (C.c_int * len(devices))(*devices)
+            self._h = self._lib.acr_host_renderer_create_multi(width, height, samples, devs, len(devices), rebalance_every, err, len(err))
+        else:
+            self._h = self._lib.acr_host_renderer_create(width, height, samples, devices[0] if devices else device, err, len(err))
         if not self._h:
             raise RuntimeError("Renderer: " + err.value.decode())
         self.width, self.height = width * samples, height * samples

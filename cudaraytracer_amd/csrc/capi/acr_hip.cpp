@@ -958,6 +958,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	p.tile_h = f->tile_h;
 	p.tiles_x = tilesX;
 	p.num_tiles = f->num_tiles;
+	p.tiles_into_frame = (tiled && f->tiles_into_frame) ? 1u : 0u;
 	p.tile_ids = tiled ? ctx->renderTiles.dev() : nullptr;
 	p.pixel_values = f->pixel_values_dev;
 	p.path_keys = f->path_keys_dev;

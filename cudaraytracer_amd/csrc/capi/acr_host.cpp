@@ -204,6 +204,26 @@ acr_host_renderer *acr_host_renderer_create(uint32_t width, uint32_t height, uin
 	}
 }
 
+acr_host_renderer *acr_host_renderer_create_multi(uint32_t width, uint32_t height, uint32_t samples, const int *devices, uint32_t num_devices,
+                                                  uint32_t rebalance_every, char *err, size_t err_len)
+{
+	try {
+		if (!devices || num_devices == 0) throw std::runtime_error("no devices given");
+		Renderer::Args args;
+		args.title = "acr";
+		args.pos = {0, 0};
+		args.dim = {width, height, samples ? samples : 1};
+		args.devices.assign(devices, devices + num_devices);
+		acr_host_renderer *r = new acr_host_renderer();
+		r->renderer = new Renderer(args);
+		r->renderer->setBalance(rebalance_every);
+		return r;
+	} catch (const std::exception &e) {
+		setErr(err, err_len, e.what());
+		return nullptr;
+	}
+}
+
 void acr_host_renderer_destroy(acr_host_renderer *r)
 {
 	if (!r) return;
@@ -297,6 +317,14 @@ int acr_host_renderer_read(acr_host_renderer *r, float *rgba, size_t num_floats,
 	return guarded(r, [&] {
 		acr_hip_ctx *ctx = r->renderer->context();
 		const size_t n = size_t(r->renderer->width()) * r->renderer->height();
+		if (!ctx) { // several GPUs: the frame is assembled on the first one by the read
+			if (primid || hit_t) throw std::runtime_error("primitive ids and hit distances are not kept when rendering across several GPUs");
+			if (num_floats != n * 4) throw std::runtime_error("size mismatch");
+			std::vector<float> tmp;
+			r->renderer->readFramebuffer(tmp);
+			if (rgba) memcpy(rgba, tmp.data(), tmp.size() * sizeof(float));
+			return;
+		}
 		if (rgba && acr_hip_read_framebuffer(ctx, rgba, num_floats) != ACR_OK) throw std::runtime_error(acr_hip_last_error(ctx));
 		if (primid && acr_hip_read_primid(ctx, primid, n) != ACR_OK) throw std::runtime_error(acr_hip_last_error(ctx));
 		if (hit_t && acr_hip_read_hit_t(ctx, hit_t, n) != ACR_OK) throw std::runtime_error(acr_hip_last_error(ctx));

@@ -1186,7 +1186,7 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
 		oldx = (tile % p.tiles_x) * p.tile_w + inx;
 		oldy = (tile / p.tiles_x) * p.tile_h + iny;
-		outSlot = size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
+		outSlot = p.tiles_into_frame ? size_t(oldy) * p.width + oldx : size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
 	} else {
 		oldx = (vblock % p.blocks_x) * 16u + lx;
 		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
@@ -1650,7 +1650,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
 		oldx = (tile % p.tiles_x) * p.tile_w + inx;
 		oldy = (tile / p.tiles_x) * p.tile_h + iny;
-		outSlot = tileNo * p.tile_w * p.tile_h + iny * p.tile_w + inx; // below 2^32: the launch's slot count is
+		outSlot = p.tiles_into_frame ? oldy * p.width + oldx : tileNo * p.tile_w * p.tile_h + iny * p.tile_w + inx; // below 2^32: the launch's slot count is, and so is the frame's
 	} else {
 		oldx = (vblock % p.blocks_x) * 16u + lx;
 		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
@@ -2326,6 +2326,7 @@ namespace
 				granted[dev][fn] = ldsBytes;
 			}
 		}
+		(void)hipGetLastError(); // an earlier, unrelated failure of some HIP call in this thread is not this launch's
 		hipLaunchKernelGGL(k, dim3(grid), dim3(acr::dev::kBlock), ldsBytes, stream, p);
 		return hipGetLastError();
 	}

@@ -39,6 +39,7 @@ namespace dev
 		uint32_t max_bounces;
 		// tile-list mode (num_tiles > 0)
 		uint32_t tile_w, tile_h, tiles_x, num_tiles;
+		uint32_t tiles_into_frame;  // the output buffers are whole frames: a listed tile's pixel (x, y) goes to y * width + x
 		const uint32_t *tile_ids;   // device
 		// buffers
 		int32_t *pixel_values;      // device or null

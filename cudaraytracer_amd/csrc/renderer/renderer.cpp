@@ -9,7 +9,8 @@ namespace acr
 	void Renderer::check(int rc, const char *what)
 	{
 		if (rc != ACR_OK)
-			throw std::runtime_error(std::string(what) + ": " + (ctx ? acr_hip_last_error(ctx) : "no context") + " (code " + std::to_string(rc) + ")");
+			throw std::runtime_error(std::string(what) + ": " + (grp ? acr_hip_group_last_error(grp) : (ctx ? acr_hip_last_error(ctx) : "no context")) +
+			                         " (code " + std::to_string(rc) + ")");
 	}
 
 	// renderer.cu:31-138 without the window, GL objects and pixel-key arrays
@@ -18,18 +19,38 @@ namespace acr
 		dim.x *= dim.z;
 		dim.y *= dim.z;
 		dim.z = 1;
-		const int rc = acr_hip_create(args.device, &ctx);
+		if (args.devices.size() > 1) {
+			// the reference's device loop keeps the first device (renderer.cu:73-104); this one keeps them all
+			if (acr_hip_group_create(uint32_t(args.devices.size()), args.devices.data(), &grp) != ACR_OK)
+				throw std::runtime_error("acr_hip_group_create failed: a GPU of the list is not usable");
+			check(acr_hip_group_resize(grp, dim.x, dim.y), "acr_hip_group_resize");
+			return;
+		}
+		const int device = args.devices.empty() ? args.device : args.devices[0];
+		const int rc = acr_hip_create(device, &ctx);
 		if (rc != ACR_OK)
-			throw std::runtime_error("acr_hip_create failed: no usable GPU " + std::to_string(args.device)); // renderer.cu:77-104 exits here
+			throw std::runtime_error("acr_hip_create failed: no usable GPU " + std::to_string(device)); // renderer.cu:77-104 exits here
 		check(acr_hip_resize(ctx, dim.x, dim.y), "acr_hip_resize");
 	}
 
-	Renderer::~Renderer() { acr_hip_destroy(ctx); }
+	Renderer::~Renderer()
+	{
+		acr_hip_group_destroy(grp);
+		acr_hip_destroy(ctx);
+	}
+
+	uint32_t Renderer::numDevices() const { return grp ? acr_hip_group_size(grp) : 1u; }
+
+	void Renderer::setBalance(uint32_t rebalanceEvery)
+	{
+		if (grp) check(acr_hip_group_set_balance(grp, rebalanceEvery, nullptr), "acr_hip_group_set_balance");
+	}
 
 	// renderer.cu:168-182
 	void Renderer::loadScene(const Scene &scene)
 	{
-		check(acr_hip_upload_scene(ctx, &scene.flatten()), "acr_hip_upload_scene");
+		if (grp) check(acr_hip_group_upload_scene(grp, &scene.flatten()), "acr_hip_group_upload_scene");
+		else check(acr_hip_upload_scene(ctx, &scene.flatten()), "acr_hip_upload_scene");
 		Camera cam = scene.camera;
 		cam.aspectRatio = float(dim.x) / float(dim.y);
 		setCamera(cam);
@@ -43,14 +64,15 @@ namespace acr
 		const math::vec3 *src[3] = {&cam.position, &cam.forward, &cam.up};
 		float *dst[3] = {c.position, c.forward, c.up};
 		for (int k = 0; k < 3; k++) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
-		check(acr_hip_set_camera(ctx, &c), "acr_hip_set_camera");
+		if (grp) check(acr_hip_group_set_camera(grp, &c), "acr_hip_group_set_camera");
+		else check(acr_hip_set_camera(ctx, &c), "acr_hip_set_camera");
 		framesNoMove = 0;
 	}
 
 	Camera Renderer::getCamera() const
 	{
 		acr_camera c{};
-		if (acr_hip_get_camera(ctx, &c) != ACR_OK) throw std::runtime_error("no camera set");
+		if ((grp ? acr_hip_group_get_camera(grp, &c) : acr_hip_get_camera(ctx, &c)) != ACR_OK) throw std::runtime_error("no camera set");
 		Camera cam;
 		cam.aspectRatio = c.aspect_ratio;
 		cam.horizontalFOV = c.horizontal_fov;
@@ -89,6 +111,14 @@ namespace acr
 		f.frames = framesNoMove;
 		f.max_bounces = maxBounces;
 		f.collect_stats = collectStats ? 1u : 0u;
+		if (grp) {
+			// the same frame, its bands dealt to the GPUs; the running mean of a band stays with the GPU that owns it
+			if (adaptive) throw std::runtime_error("the pixel-level adaptive assignment is a single-GPU feature: the group assigns bands to GPUs by the same rules");
+			check(acr_hip_group_render(grp, &f, gatherEveryFrame ? 1 : 0), "acr_hip_group_render");
+			check(acr_hip_group_sync(grp), "acr_hip_group_sync"); // cudaDeviceSynchronize (renderer.cu:422), on every GPU
+			framesNoMove++;
+			return;
+		}
 		const bool resort = adaptive && (framesNoMove + 1) % pixelMapFrameMod == 0; // renderer.cu:457
 		int32_t *votes = nullptr;
 		if (adaptive) {
@@ -111,21 +141,31 @@ namespace acr
 	void Renderer::readFramebuffer(std::vector<float> &rgba)
 	{
 		rgba.resize(size_t(dim.x) * dim.y * 4);
+		if (grp) {
+			check(acr_hip_group_read_framebuffer(grp, rgba.data(), rgba.size()), "acr_hip_group_read_framebuffer");
+			return;
+		}
 		check(acr_hip_read_framebuffer(ctx, rgba.data(), rgba.size()), "acr_hip_read_framebuffer");
 	}
 	void Renderer::readPrimitiveIds(std::vector<uint32_t> &ids)
 	{
+		if (grp) throw std::runtime_error("primitive ids are not kept when rendering across several GPUs");
 		ids.resize(size_t(dim.x) * dim.y);
 		check(acr_hip_read_primid(ctx, ids.data(), ids.size()), "acr_hip_read_primid");
 	}
 	void Renderer::readHitDistances(std::vector<float> &t)
 	{
+		if (grp) throw std::runtime_error("hit distances are not kept when rendering across several GPUs");
 		t.resize(size_t(dim.x) * dim.y);
 		check(acr_hip_read_hit_t(ctx, t.data(), t.size()), "acr_hip_read_hit_t");
 	}
 	acr_stats Renderer::stats()
 	{
 		acr_stats s{};
+		if (grp) {
+			check(acr_hip_group_read_stats(grp, &s), "acr_hip_group_read_stats");
+			return s;
+		}
 		check(acr_hip_read_stats(ctx, &s), "acr_hip_read_stats");
 		return s;
 	}

@@ -30,6 +30,10 @@ namespace acr
 			math::u32vec2 pos;
 			math::u32vec3 dim; // width, height, samples: resolution = dim.xy * dim.z (renderer.cu:42-44)
 			int device = 0;    // GPU ordinal (the reference takes the first GL-capable device, renderer.cu:76,91)
+			// More than one entry: render every frame across these GPUs (the reference stops at maxNumDevices = 1,
+			// renderer.cu:74): an acr_hip_group, bands of the frame per GPU, the frame assembled on devices[0] when it
+			// is read.  One entry is the same as `device`.  A GPU may be named more than once.
+			std::vector<int> devices;
 		};
 
 		explicit Renderer(const Args &args);
@@ -50,13 +54,20 @@ namespace acr
 		// frames without a camera move the pixel table is re-sorted by the aggregates' majority keys; a move resets
 		// table and aggregates.
 		void setAdaptiveAssignment(bool on, uint32_t every = 60) { adaptive = on; pixelMapFrameMod = every ? every : 60; }
+		// Several GPUs: how often the bands are re-dealt from measured costs (the adaptive-assignment cadence applied to
+		// GPUs; default 16 frames, 0 = never), and whether every frame is assembled on the first GPU right away (for a
+		// caller that shows every frame, as the reference does) or only when it is read (default).
+		void setBalance(uint32_t rebalanceEvery);
+		void setGatherEveryFrame(bool on) { gatherEveryFrame = on; }
+		uint32_t numDevices() const;
 		void setCamera(const Camera &cam); // places the camera directly; restarts accumulation like a move
 		Camera getCamera() const;
 
 		uint32_t width() const { return dim.x; }
 		uint32_t height() const { return dim.y; }
 		uint64_t framesWithoutMove() const { return framesNoMove; }
-		acr_hip_ctx *context() { return ctx; }
+		acr_hip_ctx *context() { return ctx; }     // one GPU; nullptr when rendering across several
+		acr_hip_group *group() { return grp; }     // several GPUs; nullptr otherwise
 
 		void readFramebuffer(std::vector<float> &rgba);
 		void readPrimitiveIds(std::vector<uint32_t> &ids);
@@ -76,6 +87,8 @@ namespace acr
 		bool adaptive = false;
 		uint32_t pixelMapFrameMod = 60; // renderer.cu:392
 		acr_hip_ctx *ctx = nullptr;
+		acr_hip_group *grp = nullptr;
+		bool gatherEveryFrame = false;
 	};
 } // namespace acr
 

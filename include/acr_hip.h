@@ -169,6 +169,12 @@ typedef struct acr_frame {
 	 * the k-th workgroup group of the launch renders block block_order_dev[k].  Results do not depend on it;
 	 * it lets the caller choose which blocks start first (see acr_hip_set_block_order).  NULL: the context's order. */
 	const uint32_t *block_order_dev;
+	/* Tile list only: where a listed tile's pixels go.  0: `screen` is the compact buffer described above.
+	 * Non-zero: `screen` (and primid_dev / hit_t_dev) are whole frames, [height][width], and every listed tile is
+	 * written in place, pixel (x, y) at y * width + x; pixels of tiles that are not listed are left alone.  This is
+	 * what lets several contexts (GPUs) each keep the running mean of their own tiles in a frame-shaped buffer
+	 * (acr_hip_group_render), for any width and tile shape. */
+	uint32_t tiles_into_frame;
 } acr_frame;
 
 /* acr_frame::collect_stats */
@@ -325,6 +331,65 @@ int acr_hip_vote_keys(acr_hip_ctx *ctx, const int32_t *votes_dev, uint64_t *path
  * finished tiles of every GPU have been gathered to GPU 0. */
 int acr_hip_scatter_tiles(acr_hip_ctx *ctx, const void *tiles_dev, const uint32_t *tile_ids, uint32_t num_tiles,
                           uint32_t tile_w, uint32_t tile_h, uint32_t width, uint32_t height, void *frame_dev);
+
+/* ---- several GPUs behind one host thread ---------------------------------
+ *
+ * The reference selects ONE device (`maxNumDevices = 1`, renderer.cu:73-104) and its render() launches one kernel
+ * on it (renderer.cu:397-423).  A group is that renderer over N devices: N contexts driven by the calling thread,
+ * the scene replicated on each, the frame cut into full-width bands of 16 rows, member i rendering a contiguous run
+ * of bands into a frame-shaped buffer on its own GPU, the pieces gathered on the FIRST member's GPU by peer-to-peer
+ * copies (each sender over its own xGMI link) when the frame is asked for.  Which bands a member renders follows
+ * the reference's adaptive-assignment rules (renderer.cu:343-355,457-461,165): an explicit table consulted by the
+ * kernel (its tile list), rebuilt every `rebalance_every` frames from costs measured while rendering (wave clock
+ * ticks per band), reset to the uniform split when the camera moves.  A device may be named more than once (several
+ * members on one GPU: useful on a one-GPU machine, to rehearse).  Status codes and error text as for a context;
+ * calls on a group are not thread-safe. */
+typedef struct acr_hip_group acr_hip_group;
+
+/* devices[0..n): GPU ordinals, member 0's GPU is where frames are assembled.  Replaces the device selection of
+ * Renderer::Renderer (renderer.cu:73-104) for n devices. */
+int acr_hip_group_create(uint32_t n, const int *devices, acr_hip_group **out);
+void acr_hip_group_destroy(acr_hip_group *grp);
+const char *acr_hip_group_last_error(const acr_hip_group *grp);
+uint32_t acr_hip_group_size(const acr_hip_group *grp);
+/* member i's context, for per-context switches (acr_hip_set_traversal, acr_hip_set_block_order); the group owns
+ * it, its stream and its buffers: do not render, resize or destroy through it */
+acr_hip_ctx *acr_hip_group_context(acr_hip_group *grp, uint32_t i);
+
+/* acr_hip_upload_scene / acr_hip_set_camera / acr_hip_get_camera / acr_hip_resize for every member (renderer.cu:
+ * 168-182,145-166,107-137).  A camera that differs from the last one also resets the band costs to uniform. */
+int acr_hip_group_upload_scene(acr_hip_group *grp, const acr_scene_soa *scene);
+int acr_hip_group_set_camera(acr_hip_group *grp, const acr_camera *camera);
+int acr_hip_group_get_camera(const acr_hip_group *grp, acr_camera *camera);
+int acr_hip_group_resize(acr_hip_group *grp, uint32_t width, uint32_t height);
+
+/* rebalance_every: the split is rebuilt from costs measured every this many frames (default 16; 0: never; the costs
+ * of frame k decide the split from frame k + 2 on, so that no frame waits for a measurement).  weights: share of the
+ * frame's cost per member, n numbers, or NULL for equal shares (default): e.g. a smaller share for member 0 when
+ * every frame is gathered, since its GPU also takes in the other members' pieces. */
+int acr_hip_group_set_balance(acr_hip_group *grp, uint32_t rebalance_every, const float *weights);
+/* begin[0..n]: member i renders bands [begin[i], begin[i + 1]) of the next frame; *num_bands = ceil(height / 16) */
+int acr_hip_group_split(const acr_hip_group *grp, uint32_t *begin, uint32_t *num_bands);
+
+/* One frame (renderer.cu:417-423) across the members; returns without waiting.  `frame` as for acr_hip_render with
+ * width / height of acr_hip_group_resize, seed, frames, max_bounces and collect_stats; the tile list, pixel table,
+ * per-tile costs, path keys and block order must be unset.
+ *   frames == 0: the frame overwrites (what the reference renders after a camera move).  Frames alternate between
+ *                two buffers per member, so the pieces of frame k may still travel while frame k + 1 renders.
+ *   frames  > 0: frame k is averaged into the running mean (renderer.cu:375-387).  Every member keeps the running
+ *                mean of the bands it owns; nothing is exchanged; when a rebalance moves a band to another member
+ *                its running mean travels from the old owner to the new one before the next frame.
+ *   gather != 0: also queue the copies that assemble this frame on member 0's GPU (otherwise that happens when
+ *                acr_hip_group_frame is called). */
+int acr_hip_group_render(acr_hip_group *grp, const acr_frame *frame, int gather);
+/* Assembles the last frame on member 0's GPU if that has not been queued yet, waits for it, and returns its device
+ * address ([height][width] float4).  The buffer is member 0's own: the next frame with frames > 0 updates member 0's
+ * bands in it, the next but one with frames == 0 overwrites it. */
+int acr_hip_group_frame(acr_hip_group *grp, void **frame_dev);
+int acr_hip_group_read_framebuffer(acr_hip_group *grp, float *rgba, size_t num_floats);
+/* ray counters of the members' last launches added up (collect_stats), kernel_ms the longest of them */
+int acr_hip_group_read_stats(acr_hip_group *grp, acr_stats *stats);
+int acr_hip_group_sync(acr_hip_group *grp);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,11 @@ typedef struct acr_host_renderer acr_host_renderer;
 /* Renderer::Renderer(Args{title,pos,dim}) without the window: dim = (width, height, samples),
  * resolution = dim.xy * dim.z (renderer.cu:42-44).  Binds GPU `device`. */
 acr_host_renderer *acr_host_renderer_create(uint32_t width, uint32_t height, uint32_t samples, int device, char *err, size_t err_len);
+/* the same renderer over several GPUs (Renderer::Args::devices; an acr_hip_group underneath): every frame's bands are
+ * dealt to the GPUs and re-dealt from measured costs every rebalance_every frames (0: never), the frame is assembled
+ * on devices[0] when it is read.  The reference stops at one device (renderer.cu:74). */
+acr_host_renderer *acr_host_renderer_create_multi(uint32_t width, uint32_t height, uint32_t samples, const int *devices, uint32_t num_devices,
+                                                  uint32_t rebalance_every, char *err, size_t err_len);
 void acr_host_renderer_destroy(acr_host_renderer *r);
 const char *acr_host_renderer_error(const acr_host_renderer *r);
 int acr_host_renderer_load_scene(acr_host_renderer *r, const acr_host_scene *scene);       /* renderer.cu:168-182 */
