@@ -56,6 +56,8 @@ def main():
     if args.soup:
         from conftest import soup_data
         data = soup_data(acr, args.soup, seed=1, edge=args.edge, extent=args.extent)
+        if args.nolights:
+            data.lights = []
         view, keep = data.pack()
         scene = acr.Scene(import_view=view, mesh_bih_depth=args.depth)
     else:
