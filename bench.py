@@ -157,8 +157,14 @@ def run_multi(w, device, world, rank, steps, warmup, rehearsal, barrier, still):
             print("[shares %s] render ms %s send ms %s shares %s" % (w.name, [round(1e3 * float(x), 3) for x in cal["render_s"]],
                   [round(1e3 * float(x), 3) for x in cal["send_s"]], [round(float(x), 3) for x in cal["weights"]]), file=sys.stderr)
     if still:
-        dr.camera_moved()  # the running mean starts with the first warm-up frame
+        dr.camera_moved()  # the running mean starts here
     first_frame = step_no[0]
+    if still:
+        # untimed frames before the warm-up, the counterpart of the single-GPU run's settle frames: three rebalance
+        # periods, so that the split has followed the measured costs and every pair of ranks that hands a band's
+        # running mean to another has exchanged something once (a pair's first exchange sets its channel up)
+        for _ in range(3 * 16):
+            dr.render_frame()
     for _ in range(warmup):
         dr.render_frame()
     dr.finish()

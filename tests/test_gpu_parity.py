@@ -895,6 +895,22 @@ def test_band_renderer_on_one_gpu(core, built, acr):
     c = b.oracle.render(w, h, seed=state["seed"], frames=0, max_bounces=2, aov=False)["counters"]
     assert rays == c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
     assert calibrate_is_noop(dr)
+    # the camera stands still: the same renderer averaging frame k into the running mean of its bands (frames = k)
+    acc = D.DistributedRenderer(w, h, bands, dev, tile_w=w, tile_h=16, rebalance_every=2, accumulate=True)
+    bands.cost_kind = "cycles"
+    screen, used = None, []
+    for k in range(5):
+        acc.render_frame()
+        used.append(state["seed"])
+        screen = b.oracle.render(w, h, seed=state["seed"], frames=k, max_bounces=2, aov=False, screen=screen)["screen"]
+    frame = acc.finish()
+    core.sync()
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), screen.view(np.uint32))
+    acc.camera_moved()
+    acc.render_frame()
+    core.sync()
+    ref = b.oracle.render(w, h, seed=state["seed"], frames=0, max_bounces=2, aov=False)["screen"]
+    assert np.array_equal(acc.finish().cpu().numpy().view(np.uint32), ref.view(np.uint32))
     core.use_own_stream()  # hip_render_tiles moved the shared context onto torch's stream
 
 
