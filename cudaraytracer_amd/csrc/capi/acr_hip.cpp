@@ -304,10 +304,11 @@ namespace
 		p.cstackOff = uint32_t(columnFloats);
 		// the whole scene in LDS: kernels compiled for four waves per SIMD, i.e. four workgroups per CU
 		const size_t waveBytes = size_t(kBlock / 64) * acr::dev::waveLdsWords() * 4;
+		const uint32_t spread = h.num_objects * (acr::dev::kWaveObjStride - acr::dev::kObjectSlots);
 		if (waveTasks && h.num_objects <= acr::dev::kWaveMaxObjects && h.num_triangles <= acr::dev::kWaveMaxTriangles &&
-		    h.num_materials <= acr::dev::kWaveMaxMaterials && size_t(h.total_slots) * 16 + stackBytes + waveBytes <= kLdsBudget) {
+		    h.num_materials <= acr::dev::kWaveMaxMaterials && size_t(h.total_slots + spread) * 16 + stackBytes + waveBytes <= kLdsBudget) {
 			p.ldsMode = 2;
-			p.stackSlot = h.total_slots;
+			p.stackSlot = h.total_slots + spread; // that kernel stages the object records one slot further apart (kWaveObjStride)
 			p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes + waveBytes;
 			p.waveOff = uint32_t(stackBytes / 4);
 			return p;

@@ -124,11 +124,15 @@ __device__ __forceinline__ float asF(uint32_t u) { return __uint_as_float(u); }
 // Scene memory view.  SMALL/LARGE say whether that part of the blob was
 // staged into LDS at the same slot offsets.  NEAR_FIRST: the interval form walks mesh trees near side first
 // (see bihTraverseNear); the default is to do so exactly when the trees live in HBM, i.e. when they are deep.
-template <bool SMALL_LDS, bool LARGE_LDS, bool NEAR_FIRST = !LARGE_LDS>
+// OBJ_STRIDE: slots from one object's record to the next.  kObjectSlots in the blob; the wave-cooperative kernel stages
+// the records kObjectSlots + 1 apart (stageSceneSpread), so that lanes reading the same word of different objects'
+// records, which is what its object tests do, do not all meet in the same LDS banks (records 256 bytes apart do).
+template <bool SMALL_LDS, bool LARGE_LDS, bool NEAR_FIRST = !LARGE_LDS, uint32_t OBJ_STRIDE = kObjectSlots>
 struct SceneMem
 {
 	static constexpr bool kLargeInLds = LARGE_LDS;
 	static constexpr bool kNearFirst = NEAR_FIRST;
+	static constexpr uint32_t kObjStride = OBJ_STRIDE;
 	const uint4 *__restrict__ g;
 	__device__ __forceinline__ uint4 small(uint32_t slot) const
 	{
@@ -838,7 +842,7 @@ template <bool FULL, bool FAST, bool PREFILTER = true, bool PARALLEL = false, cl
 __device__ __forceinline__ bool objectIntersect(const Mem &mem, const SceneHeader &sc, uint32_t obj, const Ray &r, const SlabArgs &saWorld,
                                                 WorldHit &info, const Columns &col, bool &bail, float tLimit, uint2 *winner = nullptr)
 {
-	const uint32_t os = sc.off_objects + obj * kObjectSlots;
+	const uint32_t os = sc.off_objects + obj * Mem::kObjStride;
 	const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
 	const uint32_t flags = b0.w;
 	if (PREFILTER && (flags & kObjPrefilter)) {
@@ -928,7 +932,7 @@ template <class Mem>
 __device__ __forceinline__ void objectHitDetails(const Mem &mem, const SceneHeader &sc, uint32_t obj, uint32_t tri, uint32_t material, const Ray &r,
                                                  WorldHit &info)
 {
-	const uint32_t os = sc.off_objects + obj * kObjectSlots;
+	const uint32_t os = sc.off_objects + obj * Mem::kObjStride;
 	const uint32_t flags = mem.small(os).w;
 	Ray lr;
 	{
@@ -1136,6 +1140,32 @@ __device__ __forceinline__ void stageScene(const uint4 *__restrict__ g, uint32_t
 	for (uint32_t i = threadIdx.x; i < n; i += kBlock)
 		g_lds[i] = g[i];
 	__syncthreads();
+}
+
+// The same copy with the object records kObjectSlots + 1 slots apart: blob slot i goes to LDS slot i before the object
+// table, to its place in the spread table inside it, and num_objects slots further on behind it.  spreadHeader() is the
+// scene header that describes the copy.
+__device__ __forceinline__ void stageSceneSpread(const uint4 *__restrict__ g, const SceneHeader &sc)
+{
+	const uint32_t first = sc.off_objects, end = sc.off_objects + sc.num_objects * kObjectSlots;
+	for (uint32_t i = threadIdx.x; i < sc.total_slots; i += kBlock) {
+		constexpr uint32_t extra = kWaveObjStride - kObjectSlots; // 1 (or 0 in a build that compares the two layouts)
+		uint32_t dst = i;
+		if (i >= end) dst = i + extra * sc.num_objects;
+		else if (i >= first) dst = i + extra * ((i - first) / kObjectSlots);
+		g_lds[dst] = g[i];
+	}
+	__syncthreads();
+}
+__device__ __forceinline__ SceneHeader spreadHeader(const SceneHeader &in)
+{
+	SceneHeader sc = in;
+	const uint32_t n = in.num_objects * (kWaveObjStride - kObjectSlots);
+	sc.off_objmesh += n; sc.off_meshes += n; sc.off_materials += n; sc.off_lights += n;
+	sc.off_mnodes += n; sc.off_tris += n; sc.off_normals += n;
+	sc.small_slots += n;
+	sc.total_slots += n;
+	return sc;
 }
 
 // What one pixel slot reports back to the kernel around it.
@@ -1455,7 +1485,7 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 			const uint4 b0 = nb0, b1 = nb1;
 			{
 				// after the last object the same record once more: read, never used
-				const uint32_t osn = sc.off_objects + (k + 1 < sc.num_objects ? k + 1 : k) * kObjectSlots;
+				const uint32_t osn = sc.off_objects + (k + 1 < sc.num_objects ? k + 1 : k) * Mem::kObjStride;
 				nb0 = mem.small(osn);
 				nb1 = mem.small(osn + 1);
 			}
@@ -1588,10 +1618,9 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 // Scene::intersect made by the wave as a whole (waveSceneIntersect), hence in uniform control flow: all lanes
 // walk the bounce levels and the lights in step, each with its own `alive` flag.
 template <class Mem>
-__device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
+__device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, const SceneHeader &sc, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
 	const uint32_t maxBounces = p.max_bounces;
-	const SceneHeader &sc = p.scene;
 	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
 	Columns col;
 	col.scene = ldsF + 2 * threadIdx.x;
@@ -1969,10 +1998,11 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 // (renderSlotWave).  Same grid, same block order, same list pass afterwards.
 __global__ void __launch_bounds__(kBlock, ACR_WAVE_KERNEL_WAVES) renderWaveKernel(const RenderParams p)
 {
-	const SceneHeader &sc = p.scene;
-	SceneMem<true, true> mem;
+	// this kernel's own copy of the scene: object records 17 slots apart (the host has made room: planLds)
+	SceneMem<true, true, false, kWaveObjStride> mem;
 	mem.g = p.blob;
-	stageScene(p.blob, sc.total_slots);
+	stageSceneSpread(p.blob, p.scene);
+	const SceneHeader sc = spreadHeader(p.scene);
 	const bool tiled = p.num_tiles != 0;
 	const uint64_t clock0 = ((tiled && p.tile_cycles) || p.block_cost) ? __builtin_readcyclecounter() : 0;
 	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
@@ -1981,7 +2011,7 @@ __global__ void __launch_bounds__(kBlock, ACR_WAVE_KERNEL_WAVES) renderWaveKerne
 #ifdef ACR_WAVE_DEBUG
 	const uint64_t dbgK0 = __builtin_readcyclecounter();
 #endif
-	const SlotResult res = renderSlotWave(p, mem, vblock, vtid);
+	const SlotResult res = renderSlotWave(p, sc, mem, vblock, vtid);
 #ifdef ACR_WAVE_DEBUG
 	if ((threadIdx.x & 63u) == 0) atomicAdd(&g_waveDebug[9], (unsigned long long)(__builtin_readcyclecounter() - dbgK0));
 #endif

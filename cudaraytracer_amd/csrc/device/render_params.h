@@ -84,6 +84,12 @@ namespace dev
 	constexpr uint32_t kTaskTriBits = 12;
 	constexpr uint32_t kWaveMaxTriangles = 1u << kTaskTriBits, kWaveMaxMaterials = 1u << (18u - kTaskTriBits);
 	constexpr uint32_t waveLdsWords() { return 2u * kWaveCap; }
+	// slots from one object record to the next in that kernel's LDS copy of the scene (kObjectSlots in the blob)
+#ifndef ACR_WAVE_OBJ_STRIDE
+#define ACR_WAVE_OBJ_STRIDE 17
+#endif
+	constexpr uint32_t kWaveObjStride = ACR_WAVE_OBJ_STRIDE;
+	static_assert(kWaveObjStride == kObjectSlots || kWaveObjStride == kObjectSlots + 1, "stageSceneSpread moves every record by its number");
 
 	// XCDs the XCD-aware block order is written for (workgroup i of a launch on XCD i % 8)
 	constexpr uint32_t kXcdsAssumed = 8;
