@@ -106,6 +106,39 @@ def test_every_frame_gathered_while_the_next_one_renders(acr, built):
         g.close()
 
 
+def test_group_on_scenes_that_list_pixels_and_on_trees_read_from_device_memory(acr, orc, scene_data):
+    """bands written in place (acr_frame::tiles_into_frame) by every kind of launch: pixels handed to the six-plane
+    list pass (an object with a singular transform), the wave-cooperative kernel (bounces), and mesh trees walked
+    near side first from device memory (a soup), each accumulating over frames with the split re-dealt in between"""
+    import copy
+    from conftest import Built, soup_data
+    d = copy.deepcopy(scene_data["cornell-box-cycles"])
+    k = [n["name"] for n in d.nodes].index("short_box")
+    m = np.array(d.nodes[k]["transform"], dtype=np.float32).reshape(4, 4)
+    m[2, :3] = 0.0  # the image of the local z axis: the object is squashed flat, rays that reach it are not finite in its space
+    d.nodes[k]["transform"] = [float(v) for v in m.reshape(-1)]
+    cases = [(Built(acr, orc, d), 320, 180, 3, 3),
+             (Built(acr, orc, soup_data(acr, 3000, seed=2, edge=0.3, extent=1.5), mesh_depth=10), 200, 150, 1, 2),
+             (Built(acr, orc, soup_data(acr, 60000, seed=3, edge=0.12, extent=2.0), mesh_depth=14), 256, 160, 2, 4)]
+    for b, w, h, bounces, members in cases:
+        g = acr.HipGroup([0] * members)
+        try:
+            g.upload_scene(b.scene.soa)
+            g.set_camera(b.scene.camera)
+            g.resize(w, h)
+            g.set_balance(rebalance_every=1)
+            frames = [(40 + f, f) for f in range(5)]
+            for seed, f in frames:
+                g.render(seed=seed, frames=f, max_bounces=bounces, collect_stats=1)
+            st = g.read_stats()
+            got = g.read_framebuffer()
+            assert np.array_equal(got.view(np.uint32), _oracle(b, w, h, frames, bounces).view(np.uint32))
+            c = b.oracle.render(w, h, seed=frames[-1][0], frames=0, max_bounces=bounces)["counters"]
+            assert (st.rays_primary, st.rays_shadow, st.rays_bounce) == (c["rays_primary"], c["rays_shadow"], c["rays_bounce"])
+        finally:
+            g.close()
+
+
 def test_ray_counters_and_weights(acr, built):
     b = built["cornell-box-cycles"]
     w, h = 320, 180
