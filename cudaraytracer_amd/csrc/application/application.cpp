@@ -83,7 +83,8 @@ static void usage(const char *prog)
 {
 	std::fprintf(stderr,
 	             "usage: %s <scene.blend> | --soup N   [--size WxH] [--events SCRIPT] [--frames N] [--out image.ppm|.pfm]\n"
-	             "          [--bounces N] [--seed S] [--mesh-depth D] [--device G]\n"
+	             "          [--bounces N] [--seed S] [--mesh-depth D] [--device G | --devices G0,G1,...]\n"
+	             "  --devices: every frame across these GPUs (bands of the frame per GPU, the frame assembled on G0); a GPU may be named twice\n"
 	             "  SCRIPT: w a s d = key presses, r<dx>,<dy>; = mouse drag, . = render one frame;  --frames N appends N dots\n",
 	             prog);
 }
@@ -121,6 +122,16 @@ int main(int argc, char **argv)
 		else if (a == "--soup") args.soupTriangles = unsigned(std::atoi(next()));
 		else if (a == "--mesh-depth") args.scene.meshBihDepth = size_t(std::atoi(next()));
 		else if (a == "--device") args.renderer.device = std::atoi(next());
+		else if (a == "--devices") {
+			args.renderer.devices.clear();
+			for (const char *q = next(); *q;) {
+				char *end = nullptr;
+				const long g = std::strtol(q, &end, 10);
+				if (end == q) { usage(argv[0]); return 2; }
+				args.renderer.devices.push_back(int(g));
+				q = *end == ',' ? end + 1 : end;
+			}
+		}
 		else if (a.size() && a[0] != '-') args.scene.filePath = argv[i];
 		else { usage(argv[0]); return 2; }
 	}

@@ -159,5 +159,13 @@ def test_headless_application(acr, orc, tmp_path):
     finally:
         o.close()
 
+    # the same script with every frame rendered across three contexts (the one GPU named three times): same image
+    out3 = str(tmp_path / "frame3.pfm")
+    run = subprocess.run([app, "--soup", "20000", "--mesh-depth", "12", "--size", f"{w}x{h}", "--seed", "7", "--bounces", "2",
+                          "--devices", "0,0,0", "--events", ". . w a . r30,-10; .", "--out", out3], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    with open(out, "rb") as f1, open(out3, "rb") as f3:
+        assert f1.read() == f3.read()
+
     bad = subprocess.run([app, "/nonexistent/scene.blend"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "error" in bad.stderr
