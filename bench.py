@@ -377,6 +377,7 @@ def main():
         st = core.read_stats()
         rays = st.rays_primary + st.rays_shadow + st.rays_bounce
         lds_bytes, lds_mode, interval, near_first, wave_tasks = st.lds_bytes, st.scene_in_lds, st.interval_traversal, st.near_first, st.wave_tasks
+        shared_walk = st.shared_walk
     else:
         multi = run_multi(w, device, world, rank, args.steps, args.warmup, rehearsal, barrier, still)
         elapsed, rays = multi["elapsed"], multi["rays"]
@@ -450,7 +451,7 @@ def main():
                 out["also"] = also
         if world == 1:
             tf_ = lambda v: "true" if v else "false"
-            kernel = "renderWaveKernel" if wave_tasks else "renderKernel<%s, %s, %s, false, %s>" % (
+            kernel = "renderWaveKernel" if wave_tasks else ("renderSoloKernel<%s>" % tf_(lds_mode >= 1)) if shared_walk else "renderKernel<%s, %s, %s, false, %s>" % (
                 tf_(lds_mode >= 1), tf_(lds_mode == 2), tf_(interval), tf_(interval and MAX_BOUNCES == 1))
             frame_bytes = BYTES_PER_PIXEL * WIDTH * HEIGHT
             # The roofline that binds: with the scene resident in LDS a frame's only HBM traffic is the framebuffer

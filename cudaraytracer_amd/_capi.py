@@ -96,7 +96,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("kernel_ms", C.c_float), ("lds_bytes", C.c_uint32),
                 ("scene_in_lds", C.c_uint32), ("grid_blocks", C.c_uint32), ("interval_traversal", C.c_uint32),
-                ("six_plane_pixels", C.c_uint32), ("block_order", C.c_uint32), ("near_first", C.c_uint32), ("wave_tasks", C.c_uint32)]
+                ("six_plane_pixels", C.c_uint32), ("block_order", C.c_uint32), ("near_first", C.c_uint32), ("wave_tasks", C.c_uint32),
+                ("shared_walk", C.c_uint32)]
 
 
 # every symbol include/acr_hip.h declares: name -> (restype, argtypes)

@@ -114,6 +114,8 @@ struct acr_hip_ctx
 	uint32_t parallelBits[acr::dev::kParallelWords] = {};
 	bool intervalOk = false;
 	bool leafOrderOk = false; // near-side-first walks of mesh trees can break exact ties by item position
+	bool soloScene = false;   // one object with one mesh: the tree over objects is a single leaf
+	bool soloOff = false;     // ACR_SOLO=0: such scenes are rendered by the general kernel (for comparisons)
 	int traversalMode = ACR_TRAVERSAL_AUTO;
 	uint32_t listAllCount = 0; // ACR_TRAVERSAL_LIST_PASS: source of the copy that sets the list's length
 	uint32_t *redoCount = nullptr; // device [2], used alternately by successive frames
@@ -809,6 +811,11 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	ctx->header = h;
 	ctx->intervalOk = intervalOk;
 	ctx->leafOrderOk = leafOrderOk;
+	ctx->soloScene = s->num_objects == 1 && s->obj_mesh_count[0] == 1 && sceneLevels == 1;
+	{
+		const char *e = getenv("ACR_SOLO");
+		ctx->soloOff = e && e[0] == '0';
+	}
 	ctx->sceneDepthGiven = s->scene_depth;
 	ctx->haveScene = true;
 	return ACR_OK;
@@ -1029,6 +1036,9 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
 	const bool waveKernel = fast && plan.waveOff != 0;
+	// One deep mesh read from HBM and no bounces: the kernel whose lanes share their walks through the mesh tree.
+	const bool soloKernel = fast && !listOnly && !waveKernel && plan.ldsMode != 2 && ctx->soloScene && !ctx->soloOff && f->max_bounces == 1 &&
+	                        !f->path_keys_dev && ctx->traversalMode == ACR_TRAVERSAL_AUTO;
 	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 	if (staticOnly && fast && plan.meshGlobLevels)
@@ -1094,7 +1104,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		p.block_cost = nullptr;
 		measureBlocks = false;
 	}
-	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (fast ? 1 : 0)), grid, plan.ldsBytes, ctx->stream));
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (soloKernel ? 4 : (fast ? 1 : 0))), grid, plan.ldsBytes, ctx->stream));
 	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
 	if (fast && !staticOnly) ctx->redoParity ^= 1u;
 	if (tiled) {
@@ -1151,6 +1161,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	ctx->stats.interval_traversal = fast ? 1u : 0u;
 	ctx->stats.near_first = (fast && !listOnly && plan.ldsMode != 2) ? 1u : 0u;
 	ctx->stats.wave_tasks = waveKernel ? 1u : 0u;
+	ctx->stats.shared_walk = soloKernel ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }

@@ -558,6 +558,7 @@ int acr_hip_group_read_stats(acr_hip_group *g, acr_stats *stats)
 		sum.block_order = s.block_order;
 		sum.near_first = s.near_first;
 		sum.wave_tasks = s.wave_tasks;
+		sum.shared_walk = s.shared_walk;
 	}
 	*stats = sum;
 	return ACR_OK;

@@ -504,6 +504,20 @@ __device__ __forceinline__ void bihTraverseFast(LoadNode loadNode, const SlabArg
 	}
 }
 
+#ifdef ACR_WALK_DEBUG
+// experiment builds only (make variant NAME=walkdbg DEFS=-DACR_WALK_DEBUG): how full the wave is in each part of the
+// near-side-first walk.  Sums over all walks of a run: [0] walks, [1] lane passes through the descent loop's body (two
+// node steps each), [2] the same counted once per wave (each lane adds 2^20 / lanes present), [3] [4] likewise for the
+// trips of the leaf loop (ACR_TRIS_PER_TRIP records each), [5] triangle tests made, [6] [7] likewise for the rounds
+// (descent, leaf, resumption).  Lanes present / 64 in a part = [1] / (64 * [2] / 2^20) and so on.
+__device__ unsigned long long g_walkDebug[16];
+__device__ __forceinline__ void walkDebugAdd(unsigned long long *acc, int lanePart, int wavePart)
+{
+	acc[lanePart] += 1ull;
+	acc[wavePart] += (1ull << 20) / (unsigned long long)__popcll(__ballot(true));
+}
+#endif
+
 // Near-side-first traversal, for the deep trees of scenes that live in HBM.
 //
 // bih.h:253-264 always walks the left child first, whatever the ray's direction; a deep tree then spends most of
@@ -554,12 +568,25 @@ __device__ __forceinline__ bool popNear(const LevelColumn &stack, uint32_t &pend
 // leaf's triangles are on their way, the subtree the walk will most likely resume at: 3.13 ms).  nodeCount: records of this tree (requests beyond the last one are moved onto it; what
 // they return is never used).
 // loadRun(i, out): the records i, i + 1, ... of the tree into out[].
-template <bool KEYS = false, class LoadNode, class LoadRun, class Leaf, class TCur>
-__device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, Interval box, const LevelColumn &stack,
-                                                Leaf leaf, TCur tcur, PathRec *path = nullptr)
+// State of a near-side-first walk between two of its rounds.
+struct NearWalk
 {
-	uint32_t idx = 0, level = 0, pending = 0;
-	float tminB = box.tmin, tmaxB = box.tmax;
+	uint32_t idx, level, pending;
+	float tminB, tmaxB;
+};
+
+// One round of the walk: from node w.idx down to a leaf (or to a node neither of whose children can hold a nearer hit),
+// the leaf's items, and the resumption at the deepest waiting child that still can.  Returns false when nothing waits
+// any more: the walk is over.  bihTraverseNear is rounds until then; soloWalk makes one round per lane between two looks
+// at which lanes of the wave have nothing to do.
+template <class LoadNode, class LoadRun, class Leaf, class TCur>
+__device__ __forceinline__ bool nearWalkRound(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, const LevelColumn &stack, Leaf leaf,
+                                              TCur tcur, NearWalk &w
+#ifdef ACR_WALK_DEBUG
+                                              , unsigned long long *dbg
+#endif
+)
+{
 	// One node step (bih.h:241-264 on intervals, near side first): 0 / 1 = go on with the left / right child, 2 = neither
 	// child can hold a nearer hit.
 	auto nodeStep = [&](const uint4 &n) -> uint32_t {
@@ -569,65 +596,98 @@ __device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, LoadRun loadR
 		const float tl = (asF(n.x) - oa) * ia;
 		const float tr = (asF(n.y) - oa) * ia;
 		const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
-		const float nearSideMax = tCutFar < tmaxB ? tCutFar : tmaxB;
-		const float farSideMin = tCutNear > tminB ? tCutNear : tminB;
+		const float nearSideMax = tCutFar < w.tmaxB ? tCutFar : w.tmaxB;
+		const float farSideMin = tCutNear > w.tminB ? tCutNear : w.tminB;
 		const float tc = tcur();
-		const bool hitNearSide = intervalHit(tminB, nearSideMax, tc);
-		const bool hitFarSide = intervalHit(farSideMin, tmaxB, tc);
+		const bool hitNearSide = intervalHit(w.tminB, nearSideMax, tc);
+		const bool hitFarSide = intervalHit(farSideMin, w.tmaxB, tc);
 		if (!(hitNearSide || hitFarSide))
 			return 2u;
 		if (hitNearSide && hitFarSide) {
-			pending |= 1u << level;
-			stack.store(level, make_float2(farSideMin, tmaxB));
+			w.pending |= 1u << w.level;
+			stack.store(w.level, make_float2(farSideMin, w.tmaxB));
 		}
-		if (hitNearSide) tmaxB = nearSideMax;
-		else tminB = farSideMin;
+		if (hitNearSide) w.tmaxB = nearSideMax;
+		else w.tminB = farSideMin;
 		const bool goLeft = hitNearSide != sg; // the near-side child is the left one for a positive direction
-		idx = 2 * idx + (goLeft ? 1 : 2);
-		level++;
+		w.idx = 2 * w.idx + (goLeft ? 1 : 2);
+		w.level++;
 		return goLeft ? 0u : 1u;
 	};
 	// The two children are neighbours in memory and so are the four grandchildren: one address each.  A node on the
 	// last two levels has no grandchildren (or children): the run is moved to the end of the tree, and nothing of it is used.
 	const uint32_t lastPair = nodeCount >= 2u ? nodeCount - 2u : 0u, lastQuad = nodeCount >= 4u ? nodeCount - 4u : 0u;
+#ifdef ACR_WALK_DEBUG
+	walkDebugAdd(dbg, 6, 7);
+#endif
+	// after a pop (or at the start) nothing of this subtree is at hand: the node and the two levels below it in one go
+	uint4 n = loadNode(w.idx);
+	bool popped = false;
 	for (;;) {
-		// after a pop (or at the start) nothing of this subtree is at hand: the node and the two levels below it in one go
-		uint4 n = loadNode(idx);
-		bool popped = false;
-		for (;;) {
-			// (single variables: an array that is indexed by the two decisions below ends up in scratch memory)
-			uint4 c0, c1, g0, g1, g2, g3;
-			{
-				uint4 c[2], g[4];
-				loadRun(min(2u * idx + 1u, lastPair), c);
-				loadRun(min(4u * idx + 3u, lastQuad), g);
-				c0 = c[0], c1 = c[1];
-				g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-			}
-			if ((n.w & kNodeLeafBit) != 0)
-				break;
-			const uint32_t k = nodeStep(n);
-			if (k == 2u) {
-				popped = true;
-				break;
-			}
-			n = k ? c1 : c0;
-			if ((n.w & kNodeLeafBit) != 0)
-				break;
-			const uint32_t j = nodeStep(n);
-			if (j == 2u) {
-				popped = true;
-				break;
-			}
-			n = k ? (j ? g3 : g2) : (j ? g1 : g0);
+#ifdef ACR_WALK_DEBUG
+		walkDebugAdd(dbg, 1, 2);
+#endif
+		// (single variables: an array that is indexed by the two decisions below ends up in scratch memory)
+		uint4 c0, c1, g0, g1, g2, g3;
+		{
+			uint4 c[2], g[4];
+			loadRun(min(2u * w.idx + 1u, lastPair), c);
+			loadRun(min(4u * w.idx + 3u, lastQuad), g);
+			c0 = c[0], c1 = c[1];
+			g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
 		}
-		if (!popped) {
-			if (leaf(n.z, n.w & kNodeEndMask, tminB))
-				return;
+		if ((n.w & kNodeLeafBit) != 0)
+			break;
+		const uint32_t k = nodeStep(n);
+		if (k == 2u) {
+			popped = true;
+			break;
 		}
-		if (!popNear(stack, pending, idx, level, tminB, tmaxB, tcur()))
-			return;
+		n = k ? c1 : c0;
+		if ((n.w & kNodeLeafBit) != 0)
+			break;
+		const uint32_t j = nodeStep(n);
+		if (j == 2u) {
+			popped = true;
+			break;
+		}
+		n = k ? (j ? g3 : g2) : (j ? g1 : g0);
 	}
+	if (!popped) {
+		if (leaf(n.z, n.w & kNodeEndMask, w.tminB))
+			return false;
+	}
+	return popNear(stack, w.pending, w.idx, w.level, w.tminB, w.tmaxB, tcur());
+}
+
+#ifdef ACR_WALK_DEBUG
+// adds one walk's (or one wave-cooperative walk's lane's) sums to the totals
+__device__ __forceinline__ void walkDebugFlush(const unsigned long long *a, bool histogram)
+{
+	for (int k = 0; k < 8; k++)
+		if (k != 3 && k != 4 && k != 5 && a[k]) atomicAdd(&g_walkDebug[k], a[k]);
+	if (histogram) {
+		// [8]: walks of fewer than 8 rounds, [8 + b]: of 2^(b+2) .. 2^(b+3) - 1 rounds (b = 7: 512 and more)
+		const int b = 31 - __clz(int(a[6] | 1ull)) - 2;
+		atomicAdd(&g_walkDebug[8 + (b < 0 ? 0 : b < 7 ? b : 7)], 1ull);
+	}
+}
+#endif
+
+template <bool KEYS = false, class LoadNode, class LoadRun, class Leaf, class TCur>
+__device__ __forceinline__ void bihTraverseNear(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, Interval box, const LevelColumn &stack,
+                                                Leaf leaf, TCur tcur, PathRec *path = nullptr)
+{
+	NearWalk w = {0u, 0u, 0u, box.tmin, box.tmax};
+#ifdef ACR_WALK_DEBUG
+	unsigned long long dbg[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+	while (nearWalkRound(loadNode, loadRun, nodeCount, sa, stack, leaf, tcur, w, dbg)) {
+	}
+	walkDebugFlush(dbg, true);
+#else
+	while (nearWalkRound(loadNode, loadRun, nodeCount, sa, stack, leaf, tcur, w)) {
+	}
+#endif
 }
 
 // HitInfo (geometry.h:22-27) for the world-space query, plus the primitive id
@@ -801,6 +861,15 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 		// follows (read, never tested).  Every record is requested before the first test starts.
 		static_assert(ACR_TRIS_PER_TRIP * kTriSlots <= kBlobPadSlots + kTriSlots, "a trip may read past the last triangle");
 		for (uint32_t i = start; i < end; i += ACR_TRIS_PER_TRIP) {
+#ifdef ACR_WALK_DEBUG
+			if constexpr (NEAR) {
+				unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+				walkDebugAdd(acc, 3, 4);
+				atomicAdd(&g_walkDebug[3], acc[3]);
+				atomicAdd(&g_walkDebug[4], acc[4]);
+				atomicAdd(&g_walkDebug[5], (unsigned long long)(end - i < ACR_TRIS_PER_TRIP ? end - i : ACR_TRIS_PER_TRIP));
+			}
+#endif
 			uint4 r[ACR_TRIS_PER_TRIP * kTriSlots];
 			mem.largeRun(triBase + i * kTriSlots, r);
 			__builtin_amdgcn_sched_barrier(0);
@@ -1994,6 +2063,550 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 	reportCounts(q, res, vblock, tileNo);
 }
 
+// ---- one deep mesh in HBM: the lanes of a wave share their walks ------------------------------------------------
+//
+// A ray's walk through a deep mesh tree in HBM is a chain of dependent reads, and the walks of neighbouring pixels
+// differ widely in length (10 M-triangle soup: 14 rounds on average, one ray in 200 more than 128, and a wave lasts as
+// long as the longest of its 64 walks: on average 29 % of the lanes are still walking in a round).  Here a lane without
+// a walk takes over a waiting child of a lane that has some: the subtree below it is walked by the helper with its own
+// waiting-child column, and what it finds is handed to the ray's lane when the helper is through.
+//
+// What a ray ends up with is what bihTraverseNear ends up with.  The nearest hit W (ties to the lower item number) does
+// not depend on who visits which subtree, as long as a subtree is only dropped when it starts more than kNearPruneSlack
+// behind a hit of this ray; helpers drop against their own hits and the ones the ray's lane knows of.  The order check
+// (OrderCheck) needs the nearest hit that lost: every hit any of the walkers saw and that is not W or an exact tie with
+// it.  Walkers that know less drop less and see more, so that distance can only come out nearer than in the walk by one
+// lane, which lists a pixel more, never one fewer; and a hit X with t_X <= tmin(W's leaf) lies in no subtree anybody
+// drops (its boxes start in front of every hit of the ray).
+#ifndef ACR_SOLO_GIVE_REPS
+#define ACR_SOLO_GIVE_REPS 2 // waiting children a lane may hand over between two rounds (10 M-triangle soup: 1.38 ms with 1, 1.34 with 2, 1.37 with 3)
+#endif
+#ifndef ACR_SOLO_MIN_IDLE
+#define ACR_SOLO_MIN_IDLE 16 // lanes without work before waiting children are handed over (10 M-triangle soup: 1.44 ms with 4, 1.40 with 16)
+#endif
+
+// position of the r-th set bit of mask (r < number of set bits)
+__device__ __forceinline__ uint32_t nthSetBit(uint64_t mask, uint32_t r)
+{
+	const uint32_t lo = uint32_t(mask), hi = uint32_t(mask >> 32);
+	const uint32_t c = uint32_t(__popc(lo));
+	uint32_t base = 0, m = lo;
+	if (r >= c) {
+		r -= c;
+		base = 32;
+		m = hi;
+	}
+#pragma unroll
+	for (uint32_t s = 16; s >= 1; s >>= 1) {
+		const uint32_t low = m & ((1u << s) - 1u);
+		const uint32_t c2 = uint32_t(__popc(low));
+		if (r >= c2) {
+			r -= c2;
+			base += s;
+			m >>= s;
+		} else {
+			m = low;
+		}
+	}
+	return base;
+}
+
+// what the walks of one ray have found so far (LocalHit and OrderCheck of meshIntersect)
+struct SoloFound
+{
+	float t;
+	vec3 bary;
+	uint32_t tri;
+	bool any;
+	float second, leafTmin;
+};
+
+// b's hits seen after a's, by the rules leafTriangles<NEAR> applies hit by hit
+__device__ __forceinline__ void soloMerge(SoloFound &a, float t, const vec3 &bary, uint32_t tri, float second, float leafTmin)
+{
+	bool take = t < a.t;
+	const bool tie = t == a.t;
+	float s = second < a.second ? second : a.second;
+	if (take) s = a.t < s ? a.t : s;
+	else if (!tie && t < s) s = t;
+	take = take || (tie && a.any && tri < a.tri);
+	a.second = s;
+	if (take) {
+		a.t = t;
+		a.bary = bary;
+		a.tri = tri;
+		a.leafTmin = leafTmin;
+		a.any = true;
+	}
+}
+
+__device__ __forceinline__ float shflF(float v, uint32_t src) { return __shfl(v, int(src), 64); }
+
+// Mesh::intersect (geometry.cu:52-61) below the root box test for the rays of a wave, called by all 64 lanes together.
+// wants: this lane has a ray (lr, sa; root: its interval in the mesh's box, which it hits).  R: what the ray found.
+template <class Mem>
+__device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint32_t nodeCount, uint32_t triBase, uint32_t triFirst, const LevelColumn &stack,
+                                         bool wants, const Ray &lr, const SlabArgs &sa, const Interval &root, SoloFound &R, uint32_t *nearest)
+{
+	const uint32_t lane = laneNow();
+	const uint64_t below = (1ull << lane) - 1ull;
+	R.t = FLT_MAX;
+	R.bary = vec3(0, 0, 0);
+	R.tri = 0;
+	R.any = false;
+	R.second = FLT_MAX;
+	R.leafTmin = 0.0f;
+	// the walk in hand: whose ray, the ray, where the walk is, what it has found
+	bool working = wants;
+	uint32_t owner = lane;
+	Ray jr = lr;
+	vec3 jinv = sa.invD;
+	NearWalk w = {0u, 0u, 0u, root.tmin, root.tmax};
+	LocalHit jt;
+	jt.t = FLT_MAX;
+	jt.tri = 0;
+	jt.material = 0;
+	jt.bary = vec3(0, 0, 0);
+	bool jany = false;
+	OrderCheck jorder = {FLT_MAX, 0.0f};
+#ifdef ACR_WALK_DEBUG
+	unsigned long long dbg[8] = {wants ? 1ull : 0ull, 0, 0, 0, 0, 0, 0, 0};
+#endif
+	waveSync();
+	nearest[lane] = __float_as_uint(FLT_MAX);
+	waveSync();
+	for (;;) {
+		uint64_t busy = __ballot(working);
+		if (busy == 0)
+			break;
+		// the nearest hit any walker of the ray has found so far (nearest[]: one word per lane of the wave, in LDS;
+		// hit distances are positive, and positive floats order as their bit patterns do)
+		float known = __uint_as_float(nearest[owner]);
+		for (uint32_t rep = 0; rep < uint32_t(ACR_SOLO_GIVE_REPS); rep++) {
+			if (rep != 0) busy = __ballot(working);
+			const uint32_t nIdle = 64u - uint32_t(__popcll(busy));
+			if (nIdle < uint32_t(ACR_SOLO_MIN_IDLE))
+				break;
+			const bool canGive = working && w.pending != 0u;
+			const uint64_t donors = __ballot(canGive);
+			const uint32_t nd = min(uint32_t(__popcll(donors)), nIdle);
+			if (nd == 0u)
+				break;
+			// the k-th lane with waiting children gives one to the k-th lane without work: the deepest one, which the
+			// giver would have come to next and which is nearest the ray's origin (10 M-triangle soup, 1080p: 1.44 ms
+			// per frame; giving the one nearest the root, the largest piece and the one least likely to be needed,
+			// 1.70 ms and a fifth more rounds; one lane per ray 2.37 ms)
+			float gmin = 0.0f, gmax = 0.0f;
+			uint32_t gidx = 0xFFFFFFFFu, glevel = 0u;
+			if (canGive && uint32_t(__popcll(donors & below)) < nd) {
+#ifdef ACR_SOLO_GIVE_SHALLOWEST
+				const uint32_t l = uint32_t(__ffs(int(w.pending))) - 1u;
+#else
+				const uint32_t l = 31u - uint32_t(__clz(int(w.pending)));
+#endif
+				w.pending &= ~(1u << l);
+				const float2 b = stack.load(l);
+				const float near = jt.t < known ? jt.t : known;
+				if (b.x < near * kNearPruneSlack) { // else nobody needs it any more (popNear)
+					gmin = b.x;
+					gmax = b.y;
+					gidx = (((w.idx + 1u) >> (w.level - l - 1u)) ^ 1u) - 1u; // the sibling of this path's node on level l + 1
+					glevel = l + 1u;
+				}
+			}
+			const uint32_t rank = uint32_t(__popcll(~busy & below));
+			const bool takes = !working && rank < nd;
+			const uint32_t src = takes ? nthSetBit(donors, rank) : lane;
+			const uint32_t ridx = uint32_t(__shfl(int(gidx), int(src), 64));
+			const uint32_t rlevel = uint32_t(__shfl(int(glevel), int(src), 64));
+			const float rmin = shflF(gmin, src), rmax = shflF(gmax, src);
+			const uint32_t rowner = uint32_t(__shfl(int(owner), int(src), 64));
+			const float rknown = shflF(known, src);
+			const vec3 ro(shflF(jr.o.x, src), shflF(jr.o.y, src), shflF(jr.o.z, src));
+			const vec3 rd(shflF(jr.d.x, src), shflF(jr.d.y, src), shflF(jr.d.z, src));
+			const vec3 ri(shflF(jinv.x, src), shflF(jinv.y, src), shflF(jinv.z, src));
+			if (takes && ridx != 0xFFFFFFFFu) {
+				working = true;
+				owner = rowner;
+				known = rknown;
+				jr.o = ro;
+				jr.d = rd;
+				jinv = ri;
+				w = {ridx, rlevel, 0u, rmin, rmax};
+				jt.t = FLT_MAX;
+				jt.tri = 0;
+				jt.bary = vec3(0, 0, 0);
+				jany = false;
+				jorder = {FLT_MAX, 0.0f};
+			}
+		}
+		const bool worked = working;
+		if (working) {
+			SlabArgs jsa;
+			jsa.o = jr.o;
+			jsa.invD = jinv;
+			auto loadNode = [&](uint32_t i) { return mem.large(nodeBase + i); };
+			auto loadRun = [&](uint32_t i, auto &out) { mem.largeRun(nodeBase + i, out); };
+			auto leafNear = [&](uint32_t start, uint32_t end, float leafTmin) {
+				leafTriangles<true, true>(mem, triBase, triFirst, start, end, jr, jt, jany, &jorder, leafTmin);
+				return false;
+			};
+			auto tslack = [&]() { return (jt.t < known ? jt.t : known) * kNearPruneSlack; };
+#ifdef ACR_WALK_DEBUG
+			working = nearWalkRound(loadNode, loadRun, nodeCount, jsa, stack, leafNear, tslack, w, dbg);
+#else
+			working = nearWalkRound(loadNode, loadRun, nodeCount, jsa, stack, leafNear, tslack, w);
+#endif
+		}
+		if (worked && jany) atomicMin(&nearest[owner], __float_as_uint(jt.t));
+		// a walk that is through hands what it found to the ray's lane
+		const bool through = worked && !working;
+		if (through && owner == lane && jany) soloMerge(R, jt.t, jt.bary, jt.tri, jorder.second, jorder.leafTmin);
+		uint64_t m = __ballot(through && owner != lane && jany);
+		while (m != 0) {
+			const int l = __ffsll((unsigned long long)m) - 1;
+			m &= m - 1ull;
+			const uint32_t o = uint32_t(__builtin_amdgcn_readlane(int(owner), l));
+			const float ht = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jt.t), l));
+			const vec3 hb(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(jt.bary.x), l)),
+			              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jt.bary.y), l)),
+			              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jt.bary.z), l)));
+			const uint32_t htri = uint32_t(__builtin_amdgcn_readlane(int(jt.tri), l));
+			const float hs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jorder.second), l));
+			const float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jorder.leafTmin), l));
+			if (lane == o) soloMerge(R, ht, hb, htri, hs, hl);
+		}
+		if (through) owner = lane;
+	}
+#ifdef ACR_WALK_DEBUG
+	walkDebugFlush(dbg, false);
+#endif
+}
+
+// renderSlot<true, false, true> for a scene of ONE object with ONE mesh whose tree lives in HBM (the tree over objects is
+// then a single leaf, which Scene::intersect visits without a test: bih.h:209-299 never tests the root box): what a
+// pixel's rays compute is renderSlot's, operation for operation, but the 64 lanes of a wave go through it in step and
+// walk the mesh tree together (soloWalk).  Every lane of the wave makes every call, with or without a ray.
+template <class Mem>
+__device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
+{
+	const SceneHeader &sc = p.scene;
+	float *ldsF = reinterpret_cast<float *>(g_lds + p.lds_stack_slot);
+	// this lane's waiting-child column of the mesh tree, where renderSlot has it
+	const LevelColumn stack = {reinterpret_cast<float2 *>(ldsF + 2 * threadIdx.x + 2 * sc.scene_depth * kBlock),
+	                           p.mesh_glob + (size_t(blockIdx.x) * kBlock + threadIdx.x), p.mesh_glob_levels, p.mesh_glob_stride};
+
+	// the column of the tree over objects, which nothing walks here: one word per lane of this wave for soloWalk
+	uint32_t *nearest = reinterpret_cast<uint32_t *>(ldsF) + (threadIdx.x & ~63u);
+	// the one object and its one mesh (records are read where they are used; these few numbers stay)
+	const uint32_t os = sc.off_objects;
+	const uint32_t meshId = mem.small(os + 1).w;
+	uint32_t nodeBase, nodeCount, triBase, triFirst;
+	{
+		const MeshRecord mr = loadMeshRecord(mem, sc, meshId);
+		nodeBase = __builtin_amdgcn_readfirstlane(sc.off_mnodes + mr.q1.w);
+		nodeCount = __builtin_amdgcn_readfirstlane((1u << mr.q2.y) - 1u);
+		triFirst = __builtin_amdgcn_readfirstlane(mr.q2.x);
+		triBase = sc.off_tris + triFirst * kTriSlots;
+	}
+
+	// which pixel slot: 16x16 pixels per workgroup, 8x8 per wave
+	const uint32_t lane = vtid & 63u, wave = vtid >> 6;
+	const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3), ly = (lane >> 3) + ((wave >> 1) << 3);
+	uint32_t oldx, oldy;
+	size_t outSlot;
+	SlotResult res;
+	res.tileNo = 0;
+	res.bail = false;
+	res.cnt = {0, 0, 0};
+	const bool tiled = p.num_tiles != 0;
+	if (tiled) {
+		const uint32_t bpx = p.tile_w >> 4, bpt = bpx * (p.tile_h >> 4);
+		const uint32_t tileNo = vblock / bpt, sub = vblock % bpt;
+		const uint32_t tile = p.tile_ids[tileNo];
+		res.tileNo = tileNo;
+		const uint32_t inx = ((sub % bpx) << 4) + lx, iny = ((sub / bpx) << 4) + ly;
+		oldx = (tile % p.tiles_x) * p.tile_w + inx;
+		oldy = (tile / p.tiles_x) * p.tile_h + iny;
+		outSlot = p.tiles_into_frame ? size_t(oldy) * p.width + oldx : size_t(tileNo) * p.tile_w * p.tile_h + size_t(iny) * p.tile_w + inx;
+	} else {
+		oldx = (vblock % p.blocks_x) * 16u + lx;
+		oldy = (vblock / p.blocks_x) * (kSlots / 16u) + ly;
+		outSlot = 0;
+	}
+	res.active = oldx < p.width && oldy < p.height; // renderer.cu:335-338
+
+	Ray lr; // the ray in hand, in the object's space
+	lr.o = vec3(0, 0, 0);
+	lr.d = vec3(0, 0, 1);
+	SlabArgs sa;
+	sa.o = lr.o;
+	sa.invD = vec3(1, 1, 1);
+	Interval root = {0.0f, 0.0f};
+	// Object::intersect (scene.cu:407-440) up to the walk of its mesh tree, as objectIntersect and meshIntersect make it
+	// for world ray r: 0 = the object cannot be hit (`false`, info untouched), 1 = walk the tree, 2 = the interval form
+	// cannot serve the ray.  `parallel`: the primary ray's second way in (parallelRayQualifies).
+	auto enterObject = [&](const Ray &r, const SlabArgs &saWorld, float tLimit, bool parallel) -> uint32_t {
+		const uint4 b0 = mem.small(os), b1 = mem.small(os + 1);
+		const uint32_t flags = b0.w;
+		if (flags & kObjPrefilter) {
+			const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
+			const Interval wb = boxInterval(saWorld, wmin, wmax);
+			if (!intervalHit(wb.tmin, wb.tmax, tLimit))
+				return 0u;
+		}
+		{
+			uint32_t meshBegin, meshCount;
+			const mat4 invM = loadMat4(mem, os + 2);
+			const mat3 invN = loadMat3(mem, os + 6, meshBegin, meshCount);
+			lr.o = (flags & kObjInvAffine) ? translateAffine(invM, r.o) : translate(invM, r.o);
+			lr.d = translaten(invN, r.d);
+		}
+		if (parallel || !sa.initInterval(lr)) {
+			if (!parallel || !parallelRayQualifies(sa, lr, 0u))
+				return 2u;
+		}
+		const MeshRecord mr = loadMeshRecord(mem, sc, meshId);
+		const vec3 bmin(asF(mr.q0.x), asF(mr.q0.y), asF(mr.q0.z)), bmax(asF(mr.q1.x), asF(mr.q1.y), asF(mr.q1.z));
+		root = boxInterval(sa, bmin, bmax);
+		if (!intervalHit(root.tmin, root.tmax, FLT_MAX))
+			return 0u;
+		return 1u;
+	};
+	// the hit of a finished walk in world space (scene.cu:426-431): position and distance from the world ray's origin
+	auto worldHit = [&](const vec3 &origin, float tLocal, vec3 &pw) -> float {
+		const uint32_t flags = mem.small(os).w;
+		const vec3 pl = lr.o + lr.d * tLocal;
+		const mat4 M = loadMat4(mem, os + 9);
+		pw = (flags & kObjFwdAffine) ? translateAffine(M, pl) : translate(M, pl);
+		return length(pw - origin);
+	};
+
+	// ---- the primary ray (renderer.cu:326-372) ----
+	bool alive = res.active; // the pixel still has something to compute
+	bool listed = false;      // the list pass renders it from the start
+	int index = 0;
+	RandState state;
+	state.v0 = state.v1 = state.v2 = state.v3 = state.v4 = state.d = 0;
+	uint32_t enter = 0u;
+	vec4 tail(0, 0, 0, 1); // a miss: renderer.cu:315
+	if (alive) {
+		const int width = int(p.width);
+		const int oldIndex = int(oldx) + width * int(oldy);
+		int x, y;
+		if (p.frames == 0 || !p.pixel_values) { // renderer.cu:344-352
+			if (p.pixel_values) p.pixel_values[oldIndex] = oldIndex;
+			index = oldIndex;
+			x = int(oldx);
+			y = int(oldy);
+		} else {
+			index = p.pixel_values[oldIndex];
+			x = index % width;
+			y = index / width;
+		}
+		if (!tiled) outSlot = size_t(index);
+		randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
+		const float i = 2.0f * (float(x) + randUniform(state)) * p.inv_width - 1.0f;
+		const float j = 2.0f * (float(y) + randUniform(state)) * p.inv_height - 1.0f;
+		Ray r;
+		r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+		r.d = getPixelDir(p, i, -j);
+		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
+		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
+		SlabArgs saWorld;
+		enter = 2u;
+		if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
+		if (enter == 2u) // once more, the way renderSlot tries a primary ray again
+			enter = parallelRayQualifies(saWorld, r, kParallelMaxObjects) ? enterObject(r, saWorld, FLT_MAX, true) : 2u;
+		if (enter == 2u) listed = true;
+		if (enter != 1u) alive = false;
+	}
+	SoloFound R;
+	soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive, lr, sa, root, R, nearest);
+	vec3 position(0, 0, 0), normal(0, 0, 0), lightSum(0, 0, 0);
+	uint32_t material = 0;
+	if (alive) {
+		if (R.second < FLT_MAX && R.second <= R.leafTmin) { // the visiting order could have mattered
+			listed = true;
+			alive = false;
+		} else if (!R.any) {
+			alive = false;
+		} else {
+			const vec3 cam(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+			vec3 pw;
+			const float t = worldHit(cam, R.t, pw);
+			// info as Scene::intersect leaves it: replaced iff t < info.t (scene.cu:432), which started at FLT_MAX
+			uint32_t prim = 0xFFFFFFFFu;
+			float infoT = FLT_MAX;
+			if (t < infoT) {
+				infoT = t;
+				position = pw;
+				material = loadMeshRecord(mem, sc, meshId).q0.w;
+				const uint32_t ns = sc.off_normals + R.tri * kNormalSlots;
+				const uint4 n0 = mem.large(ns), n1 = mem.large(ns + 1), n2 = mem.large(ns + 2);
+				const vec3 na(asF(n0.x), asF(n0.y), asF(n0.z));
+				const vec3 nb(asF(n0.w), asF(n1.x), asF(n1.y));
+				const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
+				const vec3 nl = R.bary.x * na + R.bary.y * nb + R.bary.z * nc; // geometry.h:141
+				uint32_t u0, u1;
+				const mat3 N = loadMat3(mem, os + 13, u0, u1);
+				normal = translaten(N, nl); // scene.cu:429
+				prim = mem.large(sc.off_tris + R.tri * kTriSlots + 2).y;
+			}
+			LateParams &q = lateParams();
+			if (q.primid) q.primid[outSlot] = prim;
+			if (q.hit_t) q.hit_t[outSlot] = infoT;
+			res.cnt.primaryHits++;
+		}
+	}
+
+	// ---- Scene::lightPoint (scene.cu:273-292), one light after the other for the whole wave ----
+	for (uint32_t li = 0; li < sc.num_lights; li++) {
+		vec3 c(0, 0, 0);
+		float lightT = 0.0f;
+		uint32_t enterS = 0u;
+		if (alive) {
+			const Light l = loadLight(mem, sc, li);
+			vec3 dir;
+			bool trace = true;
+			if (l.type == 0u) { // pointLightAccum, scene.cu:209-231
+				dir = (l.position + 0.5f * randNorm(state)) - position;
+				lightT = length(dir);
+				dir = normalize(dir);
+				const float cosTheta = max(dot(dir, normal), 0.0f);
+				c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
+				if (length(c) < epsilon()) trace = false;
+			} else { // spotLightAccum, scene.cu:234-271
+				dir = l.position - position;
+				lightT = length(dir);
+				dir = normalize(dir);
+				const float cosTheta = max(dot(dir, normal), 0.0f);
+				const float cosLight = dot(-dir, normalize(l.direction));
+				const float lightTheta = acosf(cosLight);
+				const float inner = l.outerCone - 1.57079632679f;
+				const float outer = l.innerCone;
+				const float falloff_distance = outer - inner;
+				if (fabsf(lightTheta) >= outer / 2.0f) {
+					c = vec3(0, 0, 0);
+					trace = false;
+				} else {
+					c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
+					if (length(c) < epsilon()) {
+						trace = false;
+					} else {
+						const float val = (outer / 2.0f - fabsf(lightTheta));
+						const float falloff = val / (falloff_distance / 2.0f);
+						if (double(fabsf(lightTheta)) >= double(inner) / 2.0)
+							c *= falloff;
+					}
+				}
+			}
+			if (trace) {
+				res.cnt.shadow++;
+				Ray sr;
+				sr.o = position;
+				sr.d = dir;
+				SlabArgs saWorld;
+				enterS = saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
+				if (enterS == 2u) {
+					listed = true;
+					alive = false;
+				}
+			}
+		}
+		soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive && enterS == 1u, lr, sa, root, R, nearest);
+		if (alive) {
+			if (enterS == 1u) {
+				if (R.second < FLT_MAX && R.second <= R.leafTmin) {
+					listed = true;
+					alive = false;
+				} else {
+					// scene.cu:226,266
+					float infoT = lightT;
+					if (R.any) {
+						vec3 pw;
+						const float t = worldHit(position, R.t, pw);
+						if (t < infoT) infoT = t;
+					}
+					if (infoT + epsilon() < lightT) c = vec3(0, 0, 0);
+				}
+			}
+			if (alive) lightSum += c; // scene.cu:290
+		}
+	}
+
+	if (listed) {
+		// nothing of this pixel is kept: the list pass renders it from the start
+		res.bail = true;
+		res.cnt = {0, 0, 0};
+		return res;
+	}
+	if (!res.active)
+		return res;
+	if (alive) {
+		// the rest of rayColor<1> (renderer.cu:247-313)
+		const uint32_t msl = sc.off_materials + material * kMaterialSlots;
+		const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
+		const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
+		const float refractiveIndex = asF(m0.w);
+		const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
+		const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
+		const vec3 c = ambient + diffuse * lightSum;
+		tail = vec4(c, 1) + vec4(0, 0, 0, 1); // Color4(c,1) + rayColor<0>()
+		if (refractiveIndex == 0) {
+			const vec3 source(1, 1, 1);
+			const vec3 cd = source * diffuse;
+			const vec3 cs = source * specular;
+			const float Pd = compMax(cd) / compMax(source);
+			const float Ps = compMax(cs) / compMax(source);
+			const float P = randUniform(state);
+			if (!(P < Pd) && !(P < Pd + Ps)) tail = vec4(c, 1); // absorbed (renderer.cu:282)
+		}
+	}
+	// average (renderer.cu:375-387)
+	LateParams &q = lateParams();
+	float4 *px = q.screen + outSlot;
+	if (q.frames > 0) {
+		const float4 old = *px;
+		vec4 s(old.x, old.y, old.z, old.w);
+		s = s * (float(q.frames) / float(q.frames + 1));
+		s = s + (tail / float(q.frames + 1));
+		*px = make_float4(s.x, s.y, s.z, s.w);
+	} else {
+		*px = make_float4(tail.x, tail.y, tail.z, tail.w);
+	}
+	return res;
+}
+
+// renderKernel<SMALL_LDS, false, true, false, true> for a scene of one object with one mesh: same grid, same block
+// order, same list pass afterwards.
+template <bool SMALL_LDS>
+__global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
+{
+	const SceneHeader &sc = p.scene;
+	SceneMem<SMALL_LDS, false> mem;
+	mem.g = p.blob;
+	if constexpr (SMALL_LDS) stageScene(p.blob, sc.small_slots);
+	const bool tiled = p.num_tiles != 0;
+	const uint64_t clock0 = ((tiled && p.tile_cycles) || p.block_cost) ? __builtin_readcyclecounter() : 0;
+	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
+	const uint32_t gblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
+	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
+	const SlotResult res = renderSlotSolo(p, mem, vblock, vtid);
+	LateParams &q = lateParams();
+	if (res.bail) {
+		const uint32_t at = atomicAdd(q.redo_count, 1u);
+		q.redo_list[at] = vblock * kSlots + vtid;
+	}
+	const bool firstLane = laneNow() == 0;
+	const uint32_t tileNo = tileOfBlock(q, vblock);
+	if (q.num_tiles != 0 && q.tile_cycles && firstLane)
+		atomicAdd(&q.tile_cycles[tileNo], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	if (q.block_cost && firstLane)
+		atomicAdd(&q.block_cost[vblock], uint32_t((__builtin_readcyclecounter() - clock0) >> 6));
+	reportCounts(q, res, vblock, tileNo);
+}
+
 // renderKernel for scenes resident in LDS and frames with bounces: the waves trace their rays together
 // (renderSlotWave).  Same grid, same block order, same list pass afterwards.
 __global__ void __launch_bounds__(kBlock, ACR_WAVE_KERNEL_WAVES) renderWaveKernel(const RenderParams p)
@@ -2363,7 +2976,7 @@ namespace
 } // namespace
 
 // fast == 1: interval traversal for the whole grid, then the list pass over whatever it handed back
-// (p->redo_* must be set).  fast == 3: the same with the wave-cooperative kernel (scene whole in LDS, no keys).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
+// (p->redo_* must be set).  fast == 3: the same with the wave-cooperative kernel (scene whole in LDS, no keys).  fast == 4: the same with the kernel for one deep mesh (renderSoloKernel; the caller has checked the scene and the frame).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
 // traversal for the whole grid.  p->path_keys selects the
 // variants that also record the per-pixel traversal-path key.
 template <bool KEYS>
@@ -2382,6 +2995,7 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 		if (fast == 3) k = renderWaveKernel; // ldsMode 2 only
 		if (p->max_bounces == 1)
 			k = ldsMode == 2 ? renderKernel<true, true, true, false, true> : (ldsMode == 1 ? renderKernel<true, false, true, false, true> : renderKernel<false, false, true, false, true>);
+		if (fast == 4) k = ldsMode == 1 ? renderSoloKernel<true> : renderSoloKernel<false>; // one object, one mesh, trees in HBM, max_bounces == 1
 	}
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;
@@ -2514,6 +3128,16 @@ extern "C" hipError_t acr_dev_launch_scatter_tiles(const void *tiles, const uint
 	                   tilesX, width, height, static_cast<float4 *>(frame));
 	return hipGetLastError();
 }
+
+#ifdef ACR_WALK_DEBUG
+extern "C" int acr_dev_walk_debug(unsigned long long *out, int reset)
+{
+	unsigned long long z[16] = {0};
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(acr::dev::g_walkDebug), sizeof(z)) != hipSuccess) return 1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(acr::dev::g_walkDebug), z, sizeof(z)) != hipSuccess) return 1;
+	return 0;
+}
+#endif
 
 #ifdef ACR_WAVE_DEBUG
 extern "C" int acr_dev_wave_debug(unsigned long long *out, int reset)

@@ -50,8 +50,9 @@ extern "C" {
 #define ACR_TRAVERSAL_SIX_PLANE 1  /* the slab test exactly as written (geometry.h:44-76) for every ray */
 #define ACR_TRAVERSAL_LIST_PASS 2  /* every pixel through the pass that normally renders only the listed ones: the interval form in the
                                      reference's visiting order, the six-plane form for the rays it cannot serve; slow, for tests */
-#define ACR_TRAVERSAL_NESTED    3  /* as AUTO, but frames with bounces on LDS-resident scenes also go through the kernel in which every
-                                     lane makes its object tests inside its own walk of the tree (AUTO hands them out across the wavefront) */
+#define ACR_TRAVERSAL_NESTED    3  /* as AUTO, but every frame goes through the kernel in which a lane traces its pixel's rays on its own: AUTO hands
+                                     the object tests of frames with bounces on LDS-resident scenes out across the wavefront, and lets the lanes
+                                     of a wavefront share their walks through one deep mesh tree resident in HBM (max_bounces 1) */
 
 typedef struct acr_hip_ctx acr_hip_ctx;
 
@@ -195,6 +196,7 @@ typedef struct acr_stats {
 	uint32_t block_order;          /* order in which that launch started its blocks of 16 x 16 pixel slots: ACR_BLOCK_ORDER_* */
 	uint32_t near_first;           /* 1 when that launch walked the mesh trees near side first (interval form, trees resident in HBM) */
 	uint32_t wave_tasks;           /* 1 when that launch handed its object tests out across each wavefront (frames with bounces, scene resident in LDS) */
+	uint32_t shared_walk;          /* 1 when the lanes of a wavefront shared their walks through the mesh tree (one object with one mesh resident in HBM, max_bounces 1) */
 } acr_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

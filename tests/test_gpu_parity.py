@@ -1116,3 +1116,88 @@ def test_wave_tasks_with_more_candidates_than_the_list_holds(core, acr, orc):
         screen = b.oracle.render(w, h, seed=40 + f, frames=f, max_bounces=3, screen=screen)["screen"]
     core.sync()
     assert np.array_equal(core.read_framebuffer().view(np.uint32), screen.view(np.uint32))
+
+
+def _point_lights(data, positions):
+    """adds point lights at `positions` to an ImportData, so that a pixel has several shadow rays"""
+    for k, pos in enumerate(positions):
+        at = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, float(pos[0]), float(pos[1]), float(pos[2]), 1]  # column-major translation
+        data.nodes.append(dict(name="Extra%d" % k, parent=0, transform=at, meshes=[]))
+        data.lights.append(dict(name="Extra%d" % k, type=0, position=[0, 0, 0], direction=[0, 0, -1], ambient=[2, 2, 2], diffuse=[2, 2, 2],
+                                specular=[2, 2, 2], att=[0, 1, 0], cones=[6.28, 6.28]))
+    return data
+
+
+@pytest.mark.parametrize("ntri,depth,extent,edge", [(3000, 10, 1.0, 0.08), (60000, 14, 1.0, 0.1), (400000, 17, 3.0, 0.15)])
+def test_shared_walks_of_one_deep_mesh(core, acr, orc, ntri, depth, extent, edge):
+    """One object with one mesh resident in HBM, max_bounces 1: the lanes of a wavefront share their walks through
+    the mesh tree.  Frames equal the oracle's and the one-lane-per-ray kernel's bit for bit: full frames of sizes that
+    are and are not multiples of the 16 x 16 blocks, running means over several frames, a tile list, ray counters."""
+    b = Built(acr, orc, soup_data(acr, ntri, seed=9, edge=edge, extent=extent), mesh_depth=depth)
+    load(core, b)
+    for (w, h) in ((256, 144), (203, 77)):
+        ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=1)
+        img, pid, ht, st = render(core, w, h, seed=31, frames=0, max_bounces=1)
+        assert st.shared_walk == 1 and st.near_first == 1 and st.scene_in_lds == 1  # the small tables of one object always fit
+        assert_same(img, pid, ht, st, ref)
+        assert (pid != 0xFFFFFFFF).mean() > 0.05
+        core.set_traversal(nested=True)
+        try:
+            img1, pid1, ht1, st1 = render(core, w, h, seed=31, frames=0, max_bounces=1)
+        finally:
+            core.set_traversal()
+        assert st1.shared_walk == 0 and st1.near_first == 1
+        assert np.array_equal(img1.view(np.uint32), img.view(np.uint32)) and np.array_equal(pid1, pid)
+        assert np.array_equal(ht1.view(np.uint32), ht.view(np.uint32))
+        assert (st1.rays_primary, st1.rays_shadow, st1.primary_hits) == (st.rays_primary, st.rays_shadow, st.primary_hits)
+    # running mean of four frames (renderer.cu:375-387)
+    w, h = 203, 77
+    core.resize(w, h)
+    acc = None
+    for k in range(4):
+        acc = b.oracle.render(w, h, seed=40 + k, frames=k, max_bounces=1, screen=acc)["screen"]
+        core.render(w, h, seed=40 + k, frames=k, max_bounces=1, collect_stats=True)
+        core.sync()
+        assert core.read_stats().shared_walk == 1
+        assert np.array_equal(core.read_framebuffer().view(np.uint32), acc.view(np.uint32)), "frame %d" % k
+    # a tile list, tiles out of order, one cut by the frame's edge
+    import torch
+    w, h, tw, th = 256, 144, 64, 16
+    ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=1)
+    tx = (w + tw - 1) // tw
+    ids = np.array([2 * tx + 3, 8 * tx + 1, 0, 5 * tx + 2], dtype=np.uint32)
+    tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        core.render(w, h, seed=31, frames=0, max_bounces=1, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
+        core.sync()
+        assert core.read_stats().shared_walk == 1
+    finally:
+        core.use_own_stream()
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for k, tid in enumerate(ids):
+        x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
+        ww, hh = min(tw, w - x0), min(th, h - y0)
+        assert np.array_equal(t[k, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))
+
+
+def test_shared_walks_exact_ties_and_several_lights(core, acr, orc):
+    """The shared walk on the scene where every hit is an exact tie between two copies of a triangle (the copy the
+    reference tests first must win whoever finds which), and on a soup lit by three lights (three shadow rays a pixel)."""
+    b = Built(acr, orc, duplicate_triangle_scene(acr, 30000, spread=0.05), mesh_depth=14)
+    load(core, b)
+    w, h = 256, 256
+    ref = b.oracle.render(w, h, seed=4, frames=0, max_bounces=1)
+    img, pid, ht, st = render(core, w, h, seed=4, frames=0, max_bounces=1)
+    assert st.shared_walk == 1
+    assert_same(img, pid, ht, st, ref)
+    assert 0.2 < (pid[pid != 0xFFFFFFFF] < 30000).mean() < 0.8
+    data = soup_data(acr, 60000, seed=5, edge=0.1, extent=1.0)
+    b = Built(acr, orc, _point_lights(data, [(3.0, 2.0, 4.0), (-3.0, 1.0, 3.0)]), mesh_depth=14)
+    load(core, b)
+    w, h = 240, 135
+    ref = b.oracle.render(w, h, seed=8, frames=0, max_bounces=1)
+    img, pid, ht, st = render(core, w, h, seed=8, frames=0, max_bounces=1)
+    assert st.shared_walk == 1
+    assert_same(img, pid, ht, st, ref)
+    assert st.rays_shadow > st.primary_hits  # more than one shadow ray a hit on average

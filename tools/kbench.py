@@ -170,8 +170,18 @@ def main():
     out = dict(tag=args.tag or (args.lib or "default"), scene=("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
                size=args.size, bounces=args.bounces, ms_mean=float(ms.mean()), ms_min=float(ms.min()), ms_median=float(np.median(ms)),
                rays=int(rays), grays_per_s=rays / (float(np.median(ms)) * 1e-3) / 1e9, digest=digest,
-               six_plane_pixels=st.six_plane_pixels, wave_tasks=st.wave_tasks, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
+               six_plane_pixels=st.six_plane_pixels, wave_tasks=st.wave_tasks, shared_walk=st.shared_walk, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
     print(json.dumps(out), flush=True)
+    wdbg = getattr(_capi.hip_lib(), "acr_dev_walk_debug", None)
+    if wdbg is not None:  # experiment builds (-DACR_WALK_DEBUG): how full the wave is in each part of the near-side-first walk
+        v = (C.c_ulonglong * 16)()
+        wdbg(v, 1)
+        one = float(1 << 20)
+        print("walk debug: walks %d | descent loop: %.1f passes per walk, lanes present %.3f | leaf trips: %.2f per walk, lanes present %.3f, "
+              "%.2f of %s records tested per trip | rounds: %.1f per walk, lanes present %.3f"
+              % (v[0], v[1] / max(v[0], 1), v[1] / max(64 * v[2] / one, 1e-9), v[3] / max(v[0], 1), v[3] / max(64 * v[4] / one, 1e-9),
+                 v[5] / max(v[3], 1), "ACR_TRIS_PER_TRIP", v[6] / max(v[0], 1), v[6] / max(64 * v[7] / one, 1e-9)), file=sys.stderr)
+        print("walk debug: share of walks with <8, 8-15, 16-31, ..., 256-511, 512+ rounds: " + " ".join("%.4f" % (v[8 + b] / max(v[0], 1)) for b in range(8)), file=sys.stderr)
     dbg = getattr(_capi.hip_lib(), "acr_dev_wave_debug", None)
     if dbg is not None:  # experiment builds (-DACR_WAVE_DEBUG): totals over all launches of this run
         v = (C.c_ulonglong * 16)()
