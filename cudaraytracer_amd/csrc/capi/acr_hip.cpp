@@ -286,7 +286,7 @@ namespace
 	// needs room for the six-plane form's columns next to them.
 	// waveTasks: also lay out the per-wave task tables of the wave-cooperative kernel, if the scene then still fits
 	// LDS whole (plan.waveOff != 0 says it did).
-	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false)
+	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false, bool fourWaves = false)
 	{
 		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
 		// six-plane traversal's undo column (the list pass runs in the same LDS block).
@@ -327,7 +327,11 @@ namespace
 #ifndef ACR_HBM_LDS_KB
 #define ACR_HBM_LDS_KB 52
 #endif
-		constexpr size_t kHbmBudget = size_t(ACR_HBM_LDS_KB) * 1024;
+		// fourWaves: the kernel for one deep mesh, compiled for four waves per SIMD (four workgroups share the CU's LDS)
+#ifndef ACR_SOLO_LDS_KB
+#define ACR_SOLO_LDS_KB 40
+#endif
+		const size_t kHbmBudget = size_t(fourWaves ? ACR_SOLO_LDS_KB : ACR_HBM_LDS_KB) * 1024;
 		uint32_t meshLdsLevels = h.max_mesh_depth;
 		if (splitDeepColumns) {
 			const size_t fixed = size_t(3) * colorLevels * kBlock * 4 + size_t(h.small_slots) * 16;
@@ -1028,7 +1032,11 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	// compacted across the wavefront), if its tables fit as well.
 	const bool wantWave = ctx->intervalOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && f->max_bounces > 1 && !f->path_keys_dev &&
 	                      uint64_t(grid) * kBlock < (1ull << 32); // that kernel numbers its pixel slots in 32 bits
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave);
+	// One deep mesh read from HBM and no bounces: the kernel whose lanes share their walks through the mesh tree
+	// (if the scene turns out not to fit LDS whole, which the plan says).
+	const bool wantSolo = ctx->intervalOk && ctx->leafOrderOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && ctx->soloScene && !ctx->soloOff &&
+	                      f->max_bounces == 1 && !f->path_keys_dev;
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave, wantSolo);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
 	p.lds_wave_off = plan.waveOff;
@@ -1036,9 +1044,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
 	const bool waveKernel = fast && plan.waveOff != 0;
-	// One deep mesh read from HBM and no bounces: the kernel whose lanes share their walks through the mesh tree.
-	const bool soloKernel = fast && !listOnly && !waveKernel && plan.ldsMode != 2 && ctx->soloScene && !ctx->soloOff && f->max_bounces == 1 &&
-	                        !f->path_keys_dev && ctx->traversalMode == ACR_TRAVERSAL_AUTO;
+	const bool soloKernel = fast && wantSolo && plan.ldsMode != 2;
 	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 	if (staticOnly && fast && plan.meshGlobLevels)

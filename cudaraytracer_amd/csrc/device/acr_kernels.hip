@@ -568,62 +568,65 @@ __device__ __forceinline__ bool popNear(const LevelColumn &stack, uint32_t &pend
 // leaf's triangles are on their way, the subtree the walk will most likely resume at: 3.13 ms).  nodeCount: records of this tree (requests beyond the last one are moved onto it; what
 // they return is never used).
 // loadRun(i, out): the records i, i + 1, ... of the tree into out[].
-// State of a near-side-first walk between two of its rounds.
+// The walk is made of three pieces, so that a kernel whose lanes walk together (soloWalk) can look at the wave between
+// them: nearDescend (down to a leaf), the leaf's items, popNear (up to the next waiting child).
+
+// Where a near-side-first walk stands: node, its level, the levels with a waiting child, the ray's interval in the node's box.
 struct NearWalk
 {
 	uint32_t idx, level, pending;
 	float tminB, tmaxB;
 };
 
-// One round of the walk: from node w.idx down to a leaf (or to a node neither of whose children can hold a nearer hit),
-// the leaf's items, and the resumption at the deepest waiting child that still can.  Returns false when nothing waits
-// any more: the walk is over.  bihTraverseNear is rounds until then; soloWalk makes one round per lane between two looks
-// at which lanes of the wave have nothing to do.
-template <class LoadNode, class LoadRun, class Leaf, class TCur>
-__device__ __forceinline__ bool nearWalkRound(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, const LevelColumn &stack, Leaf leaf,
-                                              TCur tcur, NearWalk &w
+// One node step (bih.h:241-264 on intervals, near side first): 0 / 1 = the walk goes on with the left / right child,
+// 2 = neither child can hold a hit nearer than tc.
+__device__ __forceinline__ uint32_t nearNodeStep(const uint4 &n, const SlabArgs &sa, const LevelColumn &stack, float tc, NearWalk &w)
+{
+	const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
+	const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
+	const bool sg = ia < 0;
+	const float tl = (asF(n.x) - oa) * ia;
+	const float tr = (asF(n.y) - oa) * ia;
+	const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
+	const float nearSideMax = tCutFar < w.tmaxB ? tCutFar : w.tmaxB;
+	const float farSideMin = tCutNear > w.tminB ? tCutNear : w.tminB;
+	const bool hitNearSide = intervalHit(w.tminB, nearSideMax, tc);
+	const bool hitFarSide = intervalHit(farSideMin, w.tmaxB, tc);
+	if (!(hitNearSide || hitFarSide))
+		return 2u;
+	if (hitNearSide && hitFarSide) {
+		w.pending |= 1u << w.level;
+		stack.store(w.level, make_float2(farSideMin, w.tmaxB));
+	}
+	if (hitNearSide) w.tmaxB = nearSideMax;
+	else w.tminB = farSideMin;
+	const bool goLeft = hitNearSide != sg; // the near-side child is the left one for a positive direction
+	w.idx = 2 * w.idx + (goLeft ? 1 : 2);
+	w.level++;
+	return goLeft ? 0u : 1u;
+}
+
+// From node w.idx (nothing of its subtree at hand) down to a leaf, two levels per memory round trip: 0 = w.idx is a
+// leaf (its record in n), 1 = neither child of the node reached can hold a nearer hit, 2 = MAX_PASSES round trips made
+// and still on the way down (only with MAX_PASSES != 0).
+// The two children are neighbours in memory and so are the four grandchildren: one address each.  A node on the
+// last two levels has no grandchildren (or children): the run is moved to the end of the tree, and nothing of it is used.
+template <uint32_t MAX_PASSES = 0, class LoadNode, class LoadRun, class TCur>
+__device__ __forceinline__ uint32_t nearDescend(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, const LevelColumn &stack, TCur tcur,
+                                                NearWalk &w, uint4 &n
 #ifdef ACR_WALK_DEBUG
-                                              , unsigned long long *dbg
+                                                , unsigned long long *dbg
 #endif
 )
 {
-	// One node step (bih.h:241-264 on intervals, near side first): 0 / 1 = go on with the left / right child, 2 = neither
-	// child can hold a nearer hit.
-	auto nodeStep = [&](const uint4 &n) -> uint32_t {
-		const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
-		const float oa = sa.o[int(axis)], ia = sa.invD[int(axis)];
-		const bool sg = ia < 0;
-		const float tl = (asF(n.x) - oa) * ia;
-		const float tr = (asF(n.y) - oa) * ia;
-		const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
-		const float nearSideMax = tCutFar < w.tmaxB ? tCutFar : w.tmaxB;
-		const float farSideMin = tCutNear > w.tminB ? tCutNear : w.tminB;
-		const float tc = tcur();
-		const bool hitNearSide = intervalHit(w.tminB, nearSideMax, tc);
-		const bool hitFarSide = intervalHit(farSideMin, w.tmaxB, tc);
-		if (!(hitNearSide || hitFarSide))
-			return 2u;
-		if (hitNearSide && hitFarSide) {
-			w.pending |= 1u << w.level;
-			stack.store(w.level, make_float2(farSideMin, w.tmaxB));
-		}
-		if (hitNearSide) w.tmaxB = nearSideMax;
-		else w.tminB = farSideMin;
-		const bool goLeft = hitNearSide != sg; // the near-side child is the left one for a positive direction
-		w.idx = 2 * w.idx + (goLeft ? 1 : 2);
-		w.level++;
-		return goLeft ? 0u : 1u;
-	};
-	// The two children are neighbours in memory and so are the four grandchildren: one address each.  A node on the
-	// last two levels has no grandchildren (or children): the run is moved to the end of the tree, and nothing of it is used.
 	const uint32_t lastPair = nodeCount >= 2u ? nodeCount - 2u : 0u, lastQuad = nodeCount >= 4u ? nodeCount - 4u : 0u;
-#ifdef ACR_WALK_DEBUG
-	walkDebugAdd(dbg, 6, 7);
-#endif
-	// after a pop (or at the start) nothing of this subtree is at hand: the node and the two levels below it in one go
-	uint4 n = loadNode(w.idx);
-	bool popped = false;
+	n = loadNode(w.idx);
+	uint32_t passes = 0;
 	for (;;) {
+		if constexpr (MAX_PASSES != 0) {
+			if (passes++ == MAX_PASSES)
+				return 2u;
+		}
 #ifdef ACR_WALK_DEBUG
 		walkDebugAdd(dbg, 1, 2);
 #endif
@@ -637,23 +640,41 @@ __device__ __forceinline__ bool nearWalkRound(LoadNode loadNode, LoadRun loadRun
 			g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
 		}
 		if ((n.w & kNodeLeafBit) != 0)
-			break;
-		const uint32_t k = nodeStep(n);
-		if (k == 2u) {
-			popped = true;
-			break;
-		}
+			return 0u;
+		const uint32_t k = nearNodeStep(n, sa, stack, tcur(), w);
+		if (k == 2u)
+			return 1u;
 		n = k ? c1 : c0;
 		if ((n.w & kNodeLeafBit) != 0)
-			break;
-		const uint32_t j = nodeStep(n);
-		if (j == 2u) {
-			popped = true;
-			break;
-		}
+			return 0u;
+		const uint32_t j = nearNodeStep(n, sa, stack, tcur(), w);
+		if (j == 2u)
+			return 1u;
 		n = k ? (j ? g3 : g2) : (j ? g1 : g0);
 	}
-	if (!popped) {
+}
+
+// One round of the walk: from node w.idx down to a leaf (or to a node neither of whose children can hold a nearer hit),
+// the leaf's items, and the resumption at the deepest waiting child that still can.  Returns false when nothing waits
+// any more: the walk is over.  bihTraverseNear is rounds until then.
+template <class LoadNode, class LoadRun, class Leaf, class TCur>
+__device__ __forceinline__ bool nearWalkRound(LoadNode loadNode, LoadRun loadRun, uint32_t nodeCount, const SlabArgs &sa, const LevelColumn &stack, Leaf leaf,
+                                              TCur tcur, NearWalk &w
+#ifdef ACR_WALK_DEBUG
+                                              , unsigned long long *dbg
+#endif
+)
+{
+#ifdef ACR_WALK_DEBUG
+	walkDebugAdd(dbg, 6, 7);
+#endif
+	uint4 n;
+#ifdef ACR_WALK_DEBUG
+	const uint32_t how = nearDescend(loadNode, loadRun, nodeCount, sa, stack, tcur, w, n, dbg);
+#else
+	const uint32_t how = nearDescend(loadNode, loadRun, nodeCount, sa, stack, tcur, w, n);
+#endif
+	if (how == 0u) {
 		if (leaf(n.z, n.w & kNodeEndMask, w.tminB))
 			return false;
 	}
@@ -748,7 +769,7 @@ struct OrderCheck
 };
 
 // Face::intersect (geometry.h:123-146) for the items [start, end) of a leaf
-template <bool NEAR = false, bool NEWTON = false, class Mem>
+template <bool NEAR = false, bool NEWTON = false, uint32_t TRIP = ACR_TRIS_PER_TRIP, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
                                               struct LocalHit &tmp, bool &intersected, OrderCheck *order = nullptr, float leafTmin = 0.0f);
 
@@ -819,7 +840,7 @@ __device__ __forceinline__ bool meshIntersect(const Mem &mem, const SceneHeader 
 	return false;
 }
 
-template <bool NEAR, bool NEWTON, class Mem>
+template <bool NEAR, bool NEWTON, uint32_t TRIP, class Mem>
 __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, uint32_t triFirst, uint32_t start, uint32_t end, const Ray &lr,
                                               LocalHit &tmp, bool &intersected, OrderCheck *order, float leafTmin)
 {
@@ -854,28 +875,28 @@ __device__ __forceinline__ void leafTriangles(const Mem &mem, uint32_t triBase, 
 			test(i, mem.large(ts), mem.large(ts + 1), mem.large(ts + 2));
 		}
 	} else {
-		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so ACR_TRIS_PER_TRIP records are fetched
+		// Triangles in HBM: a leaf's tests are a chain of memory round trips, so TRIP records (ACR_TRIS_PER_TRIP unless the caller says otherwise) are fetched
 		// per trip (the first one again where the leaf has no more) and tested in item order (10 M-triangle soup, 4.8 triangles
 		// per leaf on average: 3.06 ms with three per trip, 3.00 with four, 2.94 with five, 2.96 with six).
 		// A leaf's records follow one another in memory: one address for the trip, and past the leaf's end whatever
 		// follows (read, never tested).  Every record is requested before the first test starts.
-		static_assert(ACR_TRIS_PER_TRIP * kTriSlots <= kBlobPadSlots + kTriSlots, "a trip may read past the last triangle");
-		for (uint32_t i = start; i < end; i += ACR_TRIS_PER_TRIP) {
+		static_assert(TRIP * kTriSlots <= kBlobPadSlots + kTriSlots, "a trip may read past the last triangle");
+		for (uint32_t i = start; i < end; i += TRIP) {
 #ifdef ACR_WALK_DEBUG
 			if constexpr (NEAR) {
 				unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
 				walkDebugAdd(acc, 3, 4);
 				atomicAdd(&g_walkDebug[3], acc[3]);
 				atomicAdd(&g_walkDebug[4], acc[4]);
-				atomicAdd(&g_walkDebug[5], (unsigned long long)(end - i < ACR_TRIS_PER_TRIP ? end - i : ACR_TRIS_PER_TRIP));
+				atomicAdd(&g_walkDebug[5], (unsigned long long)(end - i < TRIP ? end - i : TRIP));
 			}
 #endif
-			uint4 r[ACR_TRIS_PER_TRIP * kTriSlots];
+			uint4 r[TRIP * kTriSlots];
 			mem.largeRun(triBase + i * kTriSlots, r);
 			__builtin_amdgcn_sched_barrier(0);
 			test(i, r[0], r[1], r[2]);
 #pragma unroll
-			for (uint32_t k = 1; k < ACR_TRIS_PER_TRIP; k++)
+			for (uint32_t k = 1; k < TRIP; k++)
 				if (i + k < end) test(i + k, r[k * kTriSlots], r[k * kTriSlots + 1], r[k * kTriSlots + 2]);
 		}
 	}
@@ -2073,16 +2094,29 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 //
 // What a ray ends up with is what bihTraverseNear ends up with.  The nearest hit W (ties to the lower item number) does
 // not depend on who visits which subtree, as long as a subtree is only dropped when it starts more than kNearPruneSlack
-// behind a hit of this ray; helpers drop against their own hits and the ones the ray's lane knows of.  The order check
+// behind a hit of this ray; every walker drops against its own hits and the nearest one any walker of the ray has
+// reported (one word per ray in LDS).  The order check
 // (OrderCheck) needs the nearest hit that lost: every hit any of the walkers saw and that is not W or an exact tie with
 // it.  Walkers that know less drop less and see more, so that distance can only come out nearer than in the walk by one
 // lane, which lists a pixel more, never one fewer; and a hit X with t_X <= tmin(W's leaf) lies in no subtree anybody
 // drops (its boxes start in front of every hit of the ray).
+//
+// Measured on the 10 M-triangle soup at 1920 x 1080 (one lane per ray: 2.37 ms per frame), each with the others at
+// their defaults: frames are bit-identical for every setting.
+#ifndef ACR_SOLO_MAX_PASSES
+#define ACR_SOLO_MAX_PASSES 3 // steps of two levels a lane goes down in one round (0: down to a leaf); 1.19 ms with 2, 1.09 with 3, 1.10 with 4
+#endif
+#ifndef ACR_SOLO_TRIS_PER_TRIP
+#define ACR_SOLO_TRIS_PER_TRIP 4 // ACR_TRIS_PER_TRIP of this kernel: with four it fits the registers of four waves per SIMD (1.12 ms with 3 and with 5)
+#endif
+#ifndef ACR_SOLO_WAVES
+#define ACR_SOLO_WAVES 4 // waves per SIMD the kernel is compiled for: 1.21 ms with three (and 52 KB of LDS columns), 1.12 with four (40 KB)
+#endif
 #ifndef ACR_SOLO_GIVE_REPS
-#define ACR_SOLO_GIVE_REPS 2 // waiting children a lane may hand over between two rounds (10 M-triangle soup: 1.38 ms with 1, 1.34 with 2, 1.37 with 3)
+#define ACR_SOLO_GIVE_REPS 2 // waiting children a lane may hand over between two rounds: 1.10 ms with 1, 1.09 with 2 and with 3
 #endif
 #ifndef ACR_SOLO_MIN_IDLE
-#define ACR_SOLO_MIN_IDLE 16 // lanes without work before waiting children are handed over (10 M-triangle soup: 1.44 ms with 4, 1.40 with 16)
+#define ACR_SOLO_MIN_IDLE 8 // lanes without work before waiting children are handed over: 1.12 / 1.11 / 1.09 / 1.12 / 1.19 ms with 2 / 4 / 8 / 16 / 24
 #endif
 
 // position of the r-th set bit of mask (r < number of set bits)
@@ -2193,9 +2227,9 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 			if (nd == 0u)
 				break;
 			// the k-th lane with waiting children gives one to the k-th lane without work: the deepest one, which the
-			// giver would have come to next and which is nearest the ray's origin (10 M-triangle soup, 1080p: 1.44 ms
-			// per frame; giving the one nearest the root, the largest piece and the one least likely to be needed,
-			// 1.70 ms and a fifth more rounds; one lane per ray 2.37 ms)
+			// giver would have come to next and which is nearest the ray's origin (giving the one nearest the root, the
+			// largest piece and the one least likely to be needed, costs a fifth more rounds: 1.70 against 1.44 ms
+			// when both were measured)
 			float gmin = 0.0f, gmax = 0.0f;
 			uint32_t gidx = 0xFFFFFFFFu, glevel = 0u;
 			if (canGive && uint32_t(__popcll(donors & below)) < nd) {
@@ -2247,16 +2281,21 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 			jsa.invD = jinv;
 			auto loadNode = [&](uint32_t i) { return mem.large(nodeBase + i); };
 			auto loadRun = [&](uint32_t i, auto &out) { mem.largeRun(nodeBase + i, out); };
-			auto leafNear = [&](uint32_t start, uint32_t end, float leafTmin) {
-				leafTriangles<true, true>(mem, triBase, triFirst, start, end, jr, jt, jany, &jorder, leafTmin);
-				return false;
-			};
 			auto tslack = [&]() { return (jt.t < known ? jt.t : known) * kNearPruneSlack; };
+			// One round: down to a leaf, the leaf's triangles, and up to the deepest waiting child that can still hold a
+			// nearer hit.  A lane that is still on its way down after ACR_SOLO_MAX_PASSES memory round trips goes on in
+			// the next round instead of keeping the rest of the wave waiting in this one.
 #ifdef ACR_WALK_DEBUG
-			working = nearWalkRound(loadNode, loadRun, nodeCount, jsa, stack, leafNear, tslack, w, dbg);
-#else
-			working = nearWalkRound(loadNode, loadRun, nodeCount, jsa, stack, leafNear, tslack, w);
+			walkDebugAdd(dbg, 6, 7);
 #endif
+			uint4 n;
+#ifdef ACR_WALK_DEBUG
+			const uint32_t how = nearDescend<ACR_SOLO_MAX_PASSES>(loadNode, loadRun, nodeCount, jsa, stack, tslack, w, n, dbg);
+#else
+			const uint32_t how = nearDescend<ACR_SOLO_MAX_PASSES>(loadNode, loadRun, nodeCount, jsa, stack, tslack, w, n);
+#endif
+			if (how == 0u) leafTriangles<true, true, ACR_SOLO_TRIS_PER_TRIP>(mem, triBase, triFirst, n.z, n.w & kNodeEndMask, jr, jt, jany, &jorder, w.tminB);
+			if (how != 2u) working = popNear(stack, w.pending, w.idx, w.level, w.tminB, w.tmaxB, tslack());
 		}
 		if (worked && jany) atomicMin(&nearest[owner], __float_as_uint(jt.t));
 		// a walk that is through hands what it found to the ray's lane
@@ -2581,7 +2620,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 // renderKernel<SMALL_LDS, false, true, false, true> for a scene of one object with one mesh: same grid, same block
 // order, same list pass afterwards.
 template <bool SMALL_LDS>
-__global__ void __launch_bounds__(kBlock, ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
+__global__ void __launch_bounds__(kBlock, ACR_SOLO_WAVES) renderSoloKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
 	SceneMem<SMALL_LDS, false> mem;
