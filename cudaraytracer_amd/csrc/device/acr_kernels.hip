@@ -2322,11 +2322,11 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 #endif
 }
 
-// renderSlot<true, false, true> for a scene of ONE object with ONE mesh whose tree lives in HBM (the tree over objects is
+// renderSlot<true, false, ONE> for a scene of one object with one mesh whose tree lives in HBM (the tree over objects is
 // then a single leaf, which Scene::intersect visits without a test: bih.h:209-299 never tests the root box): what a
 // pixel's rays compute is renderSlot's, operation for operation, but the 64 lanes of a wave go through it in step and
 // walk the mesh tree together (soloWalk).  Every lane of the wave makes every call, with or without a ray.
-template <class Mem>
+template <bool ONE, class Mem>
 __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
 	const SceneHeader &sc = p.scene;
@@ -2421,14 +2421,20 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		return length(pw - origin);
 	};
 
-	// ---- the primary ray (renderer.cu:326-372) ----
-	bool alive = res.active; // the pixel still has something to compute
-	bool listed = false;      // the list pass renders it from the start
+	// ---- scatterTrace up to the primary ray (renderer.cu:326-372) ----
+	const uint32_t maxBounces = ONE ? 1u : p.max_bounces;
+	float *cstack = ldsF + p.lds_cstack_off + threadIdx.x;
+	bool alive = res.active; // the pixel's path goes on
+	bool listed = false;      // the list pass renders the pixel from the start
 	int index = 0;
 	RandState state;
 	state.v0 = state.v1 = state.v2 = state.v3 = state.v4 = state.d = 0;
-	uint32_t enter = 0u;
-	vec4 tail(0, 0, 0, 1); // a miss: renderer.cu:315
+	Ray r; // the path's ray at this level, in world space
+	r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
+	r.d = vec3(0, 0, 1);
+	vec3 source(1, 1, 1);
+	vec4 tail(0, 0, 0, 1); // what the deepest level returns; a miss: renderer.cu:315
+	uint32_t kept = 0;     // levels whose direct term waits in cstack
 	if (alive) {
 		const int width = int(p.width);
 		const int oldIndex = int(oldx) + width * int(oldy);
@@ -2447,130 +2453,209 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		randInit(state, uint64_t(int64_t(index)) + p.seed); // renderer.cu:358
 		const float i = 2.0f * (float(x) + randUniform(state)) * p.inv_width - 1.0f;
 		const float j = 2.0f * (float(y) + randUniform(state)) * p.inv_height - 1.0f;
-		Ray r;
-		r.o = vec3(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
 		r.d = getPixelDir(p, i, -j);
 		if (p.primid) p.primid[outSlot] = 0xFFFFFFFFu;
 		if (p.hit_t) p.hit_t[outSlot] = FLT_MAX;
-		SlabArgs saWorld;
-		enter = 2u;
-		if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
-		if (enter == 2u) // once more, the way renderSlot tries a primary ray again
-			enter = parallelRayQualifies(saWorld, r, kParallelMaxObjects) ? enterObject(r, saWorld, FLT_MAX, true) : 2u;
-		if (enter == 2u) listed = true;
-		if (enter != 1u) alive = false;
-	}
-	SoloFound R;
-	soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive, lr, sa, root, R, nearest);
-	vec3 position(0, 0, 0), normal(0, 0, 0), lightSum(0, 0, 0);
-	uint32_t material = 0;
-	if (alive) {
-		if (R.second < FLT_MAX && R.second <= R.leafTmin) { // the visiting order could have mattered
-			listed = true;
-			alive = false;
-		} else if (!R.any) {
-			alive = false;
-		} else {
-			const vec3 cam(p.cam_position[0], p.cam_position[1], p.cam_position[2]);
-			vec3 pw;
-			const float t = worldHit(cam, R.t, pw);
-			// info as Scene::intersect leaves it: replaced iff t < info.t (scene.cu:432), which started at FLT_MAX
-			uint32_t prim = 0xFFFFFFFFu;
-			float infoT = FLT_MAX;
-			if (t < infoT) {
-				infoT = t;
-				position = pw;
-				material = loadMeshRecord(mem, sc, meshId).q0.w;
-				const uint32_t ns = sc.off_normals + R.tri * kNormalSlots;
-				const uint4 n0 = mem.large(ns), n1 = mem.large(ns + 1), n2 = mem.large(ns + 2);
-				const vec3 na(asF(n0.x), asF(n0.y), asF(n0.z));
-				const vec3 nb(asF(n0.w), asF(n1.x), asF(n1.y));
-				const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
-				const vec3 nl = R.bary.x * na + R.bary.y * nb + R.bary.z * nc; // geometry.h:141
-				uint32_t u0, u1;
-				const mat3 N = loadMat3(mem, os + 13, u0, u1);
-				normal = translaten(N, nl); // scene.cu:429
-				prim = mem.large(sc.off_tris + R.tri * kTriSlots + 2).y;
-			}
-			LateParams &q = lateParams();
-			if (q.primid) q.primid[outSlot] = prim;
-			if (q.hit_t) q.hit_t[outSlot] = infoT;
-			res.cnt.primaryHits++;
-		}
 	}
 
-	// ---- Scene::lightPoint (scene.cu:273-292), one light after the other for the whole wave ----
-	for (uint32_t li = 0; li < sc.num_lights; li++) {
-		vec3 c(0, 0, 0);
-		float lightT = 0.0f;
-		uint32_t enterS = 0u;
+	// ---- rayColor<max_bounces> (renderer.cu:232-324), one level after the other for the whole wave ----
+	for (uint32_t level = 0; level < maxBounces; level++) {
+		if (!ONE && __ballot(alive) == 0)
+			break;
+		uint32_t enter = 0u;
 		if (alive) {
-			const Light l = loadLight(mem, sc, li);
-			vec3 dir;
-			bool trace = true;
-			if (l.type == 0u) { // pointLightAccum, scene.cu:209-231
-				dir = (l.position + 0.5f * randNorm(state)) - position;
-				lightT = length(dir);
-				dir = normalize(dir);
-				const float cosTheta = max(dot(dir, normal), 0.0f);
-				c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
-				if (length(c) < epsilon()) trace = false;
-			} else { // spotLightAccum, scene.cu:234-271
-				dir = l.position - position;
-				lightT = length(dir);
-				dir = normalize(dir);
-				const float cosTheta = max(dot(dir, normal), 0.0f);
-				const float cosLight = dot(-dir, normalize(l.direction));
-				const float lightTheta = acosf(cosLight);
-				const float inner = l.outerCone - 1.57079632679f;
-				const float outer = l.innerCone;
-				const float falloff_distance = outer - inner;
-				if (fabsf(lightTheta) >= outer / 2.0f) {
-					c = vec3(0, 0, 0);
-					trace = false;
-				} else {
-					c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
-					if (length(c) < epsilon()) {
-						trace = false;
-					} else {
-						const float val = (outer / 2.0f - fabsf(lightTheta));
-						const float falloff = val / (falloff_distance / 2.0f);
-						if (double(fabsf(lightTheta)) >= double(inner) / 2.0)
-							c *= falloff;
-					}
+			if (level > 0) res.cnt.bounce++;
+			// Scene::intersect: the tree over objects is one leaf holding the one object
+			SlabArgs saWorld;
+			enter = 2u;
+			if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
+			if (enter == 2u && level == 0) // once more, the way renderSlot tries a primary ray again
+				enter = parallelRayQualifies(saWorld, r, kParallelMaxObjects) ? enterObject(r, saWorld, FLT_MAX, true) : 2u;
+			if (enter == 2u) listed = true;
+			if (enter != 1u) alive = false; // listed, or a miss: renderer.cu:315
+		}
+		SoloFound R;
+		soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive, lr, sa, root, R, nearest);
+		vec3 position(0, 0, 0), normal(0, 0, 0), lightSum(0, 0, 0);
+		uint32_t material = 0;
+		if (alive) {
+			if (R.second < FLT_MAX && R.second <= R.leafTmin) { // the visiting order could have mattered
+				listed = true;
+				alive = false;
+			} else if (!R.any) {
+				alive = false;
+			} else {
+				vec3 pw;
+				const float t = worldHit(r.o, R.t, pw);
+				// info as Scene::intersect leaves it: replaced iff t < info.t (scene.cu:432), which started at FLT_MAX
+				uint32_t prim = 0xFFFFFFFFu;
+				float infoT = FLT_MAX;
+				if (t < infoT) {
+					infoT = t;
+					position = pw;
+					material = loadMeshRecord(mem, sc, meshId).q0.w;
+					const uint32_t ns = sc.off_normals + R.tri * kNormalSlots;
+					const uint4 n0 = mem.large(ns), n1 = mem.large(ns + 1), n2 = mem.large(ns + 2);
+					const vec3 na(asF(n0.x), asF(n0.y), asF(n0.z));
+					const vec3 nb(asF(n0.w), asF(n1.x), asF(n1.y));
+					const vec3 nc(asF(n1.z), asF(n1.w), asF(n2.x));
+					const vec3 nl = R.bary.x * na + R.bary.y * nb + R.bary.z * nc; // geometry.h:141
+					uint32_t u0, u1;
+					const mat3 N = loadMat3(mem, os + 13, u0, u1);
+					normal = translaten(N, nl); // scene.cu:429
+					prim = mem.large(sc.off_tris + R.tri * kTriSlots + 2).y;
 				}
-			}
-			if (trace) {
-				res.cnt.shadow++;
-				Ray sr;
-				sr.o = position;
-				sr.d = dir;
-				SlabArgs saWorld;
-				enterS = saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
-				if (enterS == 2u) {
-					listed = true;
-					alive = false;
+				if (level == 0) {
+					LateParams &q = lateParams();
+					if (q.primid) q.primid[outSlot] = prim;
+					if (q.hit_t) q.hit_t[outSlot] = infoT;
+					res.cnt.primaryHits++;
 				}
 			}
 		}
-		soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive && enterS == 1u, lr, sa, root, R, nearest);
-		if (alive) {
-			if (enterS == 1u) {
-				if (R.second < FLT_MAX && R.second <= R.leafTmin) {
-					listed = true;
-					alive = false;
-				} else {
-					// scene.cu:226,266
-					float infoT = lightT;
-					if (R.any) {
-						vec3 pw;
-						const float t = worldHit(position, R.t, pw);
-						if (t < infoT) infoT = t;
+
+		// Scene::lightPoint (scene.cu:273-292), one light after the other for the whole wave
+		for (uint32_t li = 0; li < sc.num_lights; li++) {
+			vec3 c(0, 0, 0);
+			float lightT = 0.0f;
+			uint32_t enterS = 0u;
+			if (alive) {
+				const Light l = loadLight(mem, sc, li);
+				vec3 dir;
+				bool trace = true;
+				if (l.type == 0u) { // pointLightAccum, scene.cu:209-231
+					dir = (l.position + 0.5f * randNorm(state)) - position;
+					lightT = length(dir);
+					dir = normalize(dir);
+					const float cosTheta = max(dot(dir, normal), 0.0f);
+					c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
+					if (length(c) < epsilon()) trace = false;
+				} else { // spotLightAccum, scene.cu:234-271
+					dir = l.position - position;
+					lightT = length(dir);
+					dir = normalize(dir);
+					const float cosTheta = max(dot(dir, normal), 0.0f);
+					const float cosLight = dot(-dir, normalize(l.direction));
+					const float lightTheta = acosf(cosLight);
+					const float inner = l.outerCone - 1.57079632679f;
+					const float outer = l.innerCone;
+					const float falloff_distance = outer - inner;
+					if (fabsf(lightTheta) >= outer / 2.0f) {
+						c = vec3(0, 0, 0);
+						trace = false;
+					} else {
+						c = cosTheta / (l.attConstant + (l.attLinear + l.attQuadratic * lightT) * lightT) * l.diffuse;
+						if (length(c) < epsilon()) {
+							trace = false;
+						} else {
+							const float val = (outer / 2.0f - fabsf(lightTheta));
+							const float falloff = val / (falloff_distance / 2.0f);
+							if (double(fabsf(lightTheta)) >= double(inner) / 2.0)
+								c *= falloff;
+						}
 					}
-					if (infoT + epsilon() < lightT) c = vec3(0, 0, 0);
+				}
+				if (trace) {
+					res.cnt.shadow++;
+					Ray sr;
+					sr.o = position;
+					sr.d = dir;
+					SlabArgs saWorld;
+					enterS = saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
+					if (enterS == 2u) {
+						listed = true;
+						alive = false;
+					}
 				}
 			}
-			if (alive) lightSum += c; // scene.cu:290
+			soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive && enterS == 1u, lr, sa, root, R, nearest);
+			if (alive) {
+				if (enterS == 1u) {
+					if (R.second < FLT_MAX && R.second <= R.leafTmin) {
+						listed = true;
+						alive = false;
+					} else {
+						// scene.cu:226,266
+						float infoT = lightT;
+						if (R.any) {
+							vec3 pw;
+							const float t = worldHit(position, R.t, pw);
+							if (t < infoT) infoT = t;
+						}
+						if (infoT + epsilon() < lightT) c = vec3(0, 0, 0);
+					}
+				}
+				if (alive) lightSum += c; // scene.cu:290
+			}
+		}
+
+		if (alive) {
+			// the rest of this level (renderer.cu:247-313)
+			const uint32_t msl = sc.off_materials + material * kMaterialSlots;
+			const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
+			const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
+			const float refractiveIndex = asF(m0.w);
+			const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
+			const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
+			const vec3 c = ambient + diffuse * lightSum;
+			// nSource is uninitialised in the reference's translucent branch (renderer.cu:251,286-311); `source` here, as in renderSlot
+			vec3 nSource = source;
+			Ray nr;
+			nr.o = position;
+			nr.d = vec3(0, 0, 0);
+			const bool last = ONE || level + 1 == maxBounces; // the next level returns (0,0,0,1) whatever the ray
+			bool absorbed = false;
+			if (refractiveIndex == 0) {
+				const vec3 cd = source * diffuse;
+				const vec3 cs = source * specular;
+				const float Pd = compMax(cd) / compMax(source);
+				const float Ps = compMax(cs) / compMax(source);
+				const float P = randUniform(state);
+				if (P < Pd) {
+					if (!last) {
+						nSource = cd * (1 / Pd);
+						nr.d = randomHemi(normal, state);
+					}
+				} else if (P < Pd + Ps) {
+					if (!last) {
+						nSource = cs * (1 / Ps);
+						nr.d = reflect(r.d, normal);
+					}
+				} else {
+					absorbed = true; // renderer.cu:282
+				}
+			} else if (!last) {
+				float n1, n2;
+				vec3 norm = normal;
+				if (dot(r.d, norm) < 0) {
+					n1 = refractiveIndex;
+					n2 = 1;
+				} else {
+					n1 = 1;
+					n2 = refractiveIndex;
+					norm *= -1.0f;
+				}
+				const float Rs = rSchlick2(r.d, norm, n1, n2);
+				if (randUniform(state) >= Rs)
+					nr.d = refract(r.d, norm, n1 / n2);
+				else
+					nr.d = reflect(r.d, norm);
+			}
+			if (absorbed) {
+				tail = vec4(c, 1);
+				alive = false;
+			} else if (last) { // Color4(c,1) + rayColor<0>() = Color4(c,1) + (0,0,0,1)
+				tail = vec4(c, 1) + vec4(0, 0, 0, 1);
+				alive = false;
+			} else {
+				// Color4(c,1) + rayColor<N-1>(...): remember c, add after the deeper levels
+				cstack[(3 * level + 0) * kBlock] = c.x;
+				cstack[(3 * level + 1) * kBlock] = c.y;
+				cstack[(3 * level + 2) * kBlock] = c.z;
+				kept = level + 1;
+				r = nr;
+				source = nSource;
+			}
 		}
 	}
 
@@ -2582,24 +2667,12 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 	}
 	if (!res.active)
 		return res;
-	if (alive) {
-		// the rest of rayColor<1> (renderer.cu:247-313)
-		const uint32_t msl = sc.off_materials + material * kMaterialSlots;
-		const uint4 m0 = mem.small(msl), m1 = mem.small(msl + 1), m2 = mem.small(msl + 2);
-		const vec3 ambient(asF(m0.x), asF(m0.y), asF(m0.z));
-		const float refractiveIndex = asF(m0.w);
-		const vec3 diffuse(asF(m1.x), asF(m1.y), asF(m1.z));
-		const vec3 specular(asF(m2.x), asF(m2.y), asF(m2.z));
-		const vec3 c = ambient + diffuse * lightSum;
-		tail = vec4(c, 1) + vec4(0, 0, 0, 1); // Color4(c,1) + rayColor<0>()
-		if (refractiveIndex == 0) {
-			const vec3 source(1, 1, 1);
-			const vec3 cd = source * diffuse;
-			const vec3 cs = source * specular;
-			const float Pd = compMax(cd) / compMax(source);
-			const float Ps = compMax(cs) / compMax(source);
-			const float P = randUniform(state);
-			if (!(P < Pd) && !(P < Pd + Ps)) tail = vec4(c, 1); // absorbed (renderer.cu:282)
+	vec4 contribution = tail;
+	if constexpr (!ONE) {
+		while (kept > 0) {
+			kept--;
+			const vec4 cl(cstack[(3 * kept + 0) * kBlock], cstack[(3 * kept + 1) * kBlock], cstack[(3 * kept + 2) * kBlock], 1.0f);
+			contribution = cl + contribution;
 		}
 	}
 	// average (renderer.cu:375-387)
@@ -2609,18 +2682,18 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		const float4 old = *px;
 		vec4 s(old.x, old.y, old.z, old.w);
 		s = s * (float(q.frames) / float(q.frames + 1));
-		s = s + (tail / float(q.frames + 1));
+		s = s + (contribution / float(q.frames + 1));
 		*px = make_float4(s.x, s.y, s.z, s.w);
 	} else {
-		*px = make_float4(tail.x, tail.y, tail.z, tail.w);
+		*px = make_float4(contribution.x, contribution.y, contribution.z, contribution.w);
 	}
 	return res;
 }
 
 // renderKernel<SMALL_LDS, false, true, false, true> for a scene of one object with one mesh: same grid, same block
 // order, same list pass afterwards.
-template <bool SMALL_LDS>
-__global__ void __launch_bounds__(kBlock, ACR_SOLO_WAVES) renderSoloKernel(const RenderParams p)
+template <bool SMALL_LDS, bool ONE>
+__global__ void __launch_bounds__(kBlock, ONE ? ACR_SOLO_WAVES : ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
 	SceneMem<SMALL_LDS, false> mem;
@@ -2631,7 +2704,7 @@ __global__ void __launch_bounds__(kBlock, ACR_SOLO_WAVES) renderSoloKernel(const
 	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
 	const uint32_t gblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
 	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
-	const SlotResult res = renderSlotSolo(p, mem, vblock, vtid);
+	const SlotResult res = renderSlotSolo<ONE>(p, mem, vblock, vtid);
 	LateParams &q = lateParams();
 	if (res.bail) {
 		const uint32_t at = atomicAdd(q.redo_count, 1u);
@@ -3034,7 +3107,10 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 		if (fast == 3) k = renderWaveKernel; // ldsMode 2 only
 		if (p->max_bounces == 1)
 			k = ldsMode == 2 ? renderKernel<true, true, true, false, true> : (ldsMode == 1 ? renderKernel<true, false, true, false, true> : renderKernel<false, false, true, false, true>);
-		if (fast == 4) k = ldsMode == 1 ? renderSoloKernel<true> : renderSoloKernel<false>; // one object, one mesh, trees in HBM, max_bounces == 1
+		if (fast == 4) { // one object, one mesh, trees in HBM
+			if (p->max_bounces == 1) k = ldsMode == 1 ? renderSoloKernel<true, true> : renderSoloKernel<false, true>;
+			else k = ldsMode == 1 ? renderSoloKernel<true, false> : renderSoloKernel<false, false>;
+		}
 	}
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;

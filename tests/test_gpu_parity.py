@@ -1129,47 +1129,50 @@ def _point_lights(data, positions):
 
 
 @pytest.mark.parametrize("ntri,depth,extent,edge", [(3000, 10, 1.0, 0.08), (60000, 14, 1.0, 0.1), (400000, 17, 3.0, 0.15)])
-def test_shared_walks_of_one_deep_mesh(core, acr, orc, ntri, depth, extent, edge):
-    """One object with one mesh resident in HBM, max_bounces 1: the lanes of a wavefront share their walks through
-    the mesh tree.  Frames equal the oracle's and the one-lane-per-ray kernel's bit for bit: full frames of sizes that
-    are and are not multiples of the 16 x 16 blocks, running means over several frames, a tile list, ray counters."""
+@pytest.mark.parametrize("bounces", [1, 4])
+def test_shared_walks_of_one_deep_mesh(core, acr, orc, ntri, depth, extent, edge, bounces):
+    """One object with one mesh resident in HBM: the lanes of a wavefront share their walks through the mesh tree,
+    in frames without bounces (max_bounces 1, a kernel variant of its own) and with them.  Frames equal the oracle's
+    and the one-lane-per-ray kernel's bit for bit: full frames of sizes that are and are not multiples of the 16 x 16
+    blocks, running means over several frames, a tile list, ray counters."""
     b = Built(acr, orc, soup_data(acr, ntri, seed=9, edge=edge, extent=extent), mesh_depth=depth)
     load(core, b)
     for (w, h) in ((256, 144), (203, 77)):
-        ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=1)
-        img, pid, ht, st = render(core, w, h, seed=31, frames=0, max_bounces=1)
+        ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=bounces)
+        img, pid, ht, st = render(core, w, h, seed=31, frames=0, max_bounces=bounces)
         assert st.shared_walk == 1 and st.near_first == 1 and st.scene_in_lds == 1  # the small tables of one object always fit
         assert_same(img, pid, ht, st, ref)
         assert (pid != 0xFFFFFFFF).mean() > 0.05
         core.set_traversal(nested=True)
         try:
-            img1, pid1, ht1, st1 = render(core, w, h, seed=31, frames=0, max_bounces=1)
+            img1, pid1, ht1, st1 = render(core, w, h, seed=31, frames=0, max_bounces=bounces)
         finally:
             core.set_traversal()
         assert st1.shared_walk == 0 and st1.near_first == 1
         assert np.array_equal(img1.view(np.uint32), img.view(np.uint32)) and np.array_equal(pid1, pid)
         assert np.array_equal(ht1.view(np.uint32), ht.view(np.uint32))
-        assert (st1.rays_primary, st1.rays_shadow, st1.primary_hits) == (st.rays_primary, st.rays_shadow, st.primary_hits)
+        assert (st1.rays_primary, st1.rays_shadow, st1.rays_bounce, st1.primary_hits) == (st.rays_primary, st.rays_shadow, st.rays_bounce, st.primary_hits)
+        assert (st.rays_bounce > 0) == (bounces > 1)
     # running mean of four frames (renderer.cu:375-387)
     w, h = 203, 77
     core.resize(w, h)
     acc = None
     for k in range(4):
-        acc = b.oracle.render(w, h, seed=40 + k, frames=k, max_bounces=1, screen=acc)["screen"]
-        core.render(w, h, seed=40 + k, frames=k, max_bounces=1, collect_stats=True)
+        acc = b.oracle.render(w, h, seed=40 + k, frames=k, max_bounces=bounces, screen=acc)["screen"]
+        core.render(w, h, seed=40 + k, frames=k, max_bounces=bounces, collect_stats=True)
         core.sync()
         assert core.read_stats().shared_walk == 1
         assert np.array_equal(core.read_framebuffer().view(np.uint32), acc.view(np.uint32)), "frame %d" % k
     # a tile list, tiles out of order, one cut by the frame's edge
     import torch
     w, h, tw, th = 256, 144, 64, 16
-    ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=1)
+    ref = b.oracle.render(w, h, seed=31, frames=0, max_bounces=bounces)
     tx = (w + tw - 1) // tw
     ids = np.array([2 * tx + 3, 8 * tx + 1, 0, 5 * tx + 2], dtype=np.uint32)
     tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
-        core.render(w, h, seed=31, frames=0, max_bounces=1, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
+        core.render(w, h, seed=31, frames=0, max_bounces=bounces, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
         core.sync()
         assert core.read_stats().shared_walk == 1
     finally:
@@ -1196,8 +1199,9 @@ def test_shared_walks_exact_ties_and_several_lights(core, acr, orc):
     b = Built(acr, orc, _point_lights(data, [(3.0, 2.0, 4.0), (-3.0, 1.0, 3.0)]), mesh_depth=14)
     load(core, b)
     w, h = 240, 135
-    ref = b.oracle.render(w, h, seed=8, frames=0, max_bounces=1)
-    img, pid, ht, st = render(core, w, h, seed=8, frames=0, max_bounces=1)
-    assert st.shared_walk == 1
-    assert_same(img, pid, ht, st, ref)
-    assert st.rays_shadow > st.primary_hits  # more than one shadow ray a hit on average
+    for bounces in (1, 3):
+        ref = b.oracle.render(w, h, seed=8, frames=0, max_bounces=bounces)
+        img, pid, ht, st = render(core, w, h, seed=8, frames=0, max_bounces=bounces)
+        assert st.shared_walk == 1
+        assert_same(img, pid, ht, st, ref)
+        assert st.rays_shadow > st.primary_hits  # more than one shadow ray a hit on average
