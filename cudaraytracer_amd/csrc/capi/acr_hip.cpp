@@ -1036,8 +1036,9 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	// (if the scene turns out not to fit LDS whole, which the plan says).
 	const bool wantSolo = ctx->intervalOk && ctx->leafOrderOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && ctx->soloScene && !ctx->soloOff &&
 	                      f->max_bounces >= 1 && !f->path_keys_dev;
-	// (the variant of that kernel for frames without bounces is compiled for four waves per SIMD)
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave, wantSolo && f->max_bounces == 1);
+	// (the variant of that kernel for frames without bounces is compiled for four waves per SIMD, and its columns then
+	// get a quarter of a CU's LDS, the levels above them global memory: not for the launch that may allocate nothing)
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave, wantSolo && f->max_bounces == 1 && !staticOnly);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
 	p.lds_wave_off = plan.waveOff;

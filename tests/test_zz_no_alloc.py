@@ -116,7 +116,13 @@ def test_render_static_refuses_what_would_allocate(acr, orc, built):
         deep = Built(acr, orc, soup_data(acr, 200000, seed=4, edge=0.12, extent=2.0), mesh_depth=18)
         core.upload_scene(deep.scene.soa)
         core.set_camera(deep.scene.camera)
-        core.render(64, 64, static=True)  # one bounce level: every level of the waiting-child column fits LDS
+        core.render(64, 64, static=True, collect_stats=True)  # one bounce level: every level of the waiting-child column fits LDS
+        core.sync()
+        assert core.read_stats().shared_walk == 1  # one deep mesh: the lanes share their walks here too
+        fixed = core.read_framebuffer().copy()
+        core.render(64, 64)
+        core.sync()
+        assert np.array_equal(core.read_framebuffer().view(np.uint32), fixed.view(np.uint32))
         with pytest.raises(RuntimeError, match="levels deeper"):
             core.render(64, 64, max_bounces=12, static=True)  # the direct-term columns of 11 levels push part of it out
         core.render(64, 64, max_bounces=12)  # the allocating entry point still serves it
