@@ -2233,11 +2233,7 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 			float gmin = 0.0f, gmax = 0.0f;
 			uint32_t gidx = 0xFFFFFFFFu, glevel = 0u;
 			if (canGive && uint32_t(__popcll(donors & below)) < nd) {
-#ifdef ACR_SOLO_GIVE_SHALLOWEST
-				const uint32_t l = uint32_t(__ffs(int(w.pending))) - 1u;
-#else
 				const uint32_t l = 31u - uint32_t(__clz(int(w.pending)));
-#endif
 				w.pending &= ~(1u << l);
 				const float2 b = stack.load(l);
 				const float near = jt.t < known ? jt.t : known;
