@@ -278,6 +278,7 @@ namespace
 		size_t ldsBytes;
 		uint32_t cstackOff;       // floats from the first column to the direct-term columns
 		uint32_t waveOff;         // floats from the first column to the per-wave task tables; 0: the launch has none
+		uint32_t wordsOff;        // floats from the first column to one word per work-item behind the columns (sharedWords)
 		uint32_t meshGlobLevels;  // top levels of the mesh tree's waiting-child column kept in global memory
 	};
 
@@ -286,7 +287,7 @@ namespace
 	// needs room for the six-plane form's columns next to them.
 	// waveTasks: also lay out the per-wave task tables of the wave-cooperative kernel, if the scene then still fits
 	// LDS whole (plan.waveOff != 0 says it did).
-	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false, bool fourWaves = false)
+	LaunchPlan planLds(const SceneHeader &h, uint32_t colorLevels, bool splitDeepColumns, bool waveTasks = false, bool fourWaves = false, bool sharedWords = false)
 	{
 		// Per tree level and lane: two floats for the interval traversal's waiting-child column, one for the
 		// six-plane traversal's undo column (the list pass runs in the same LDS block).
@@ -300,6 +301,7 @@ namespace
 		};
 		LaunchPlan p;
 		p.waveOff = 0;
+		p.wordsOff = 0;
 		p.meshGlobLevels = 0;
 		size_t columnFloats = 0;
 		size_t stackBytes = layout(h.max_mesh_depth, columnFloats);
@@ -334,7 +336,8 @@ namespace
 		const size_t kHbmBudget = size_t(fourWaves ? ACR_SOLO_LDS_KB : ACR_HBM_LDS_KB) * 1024;
 		uint32_t meshLdsLevels = h.max_mesh_depth;
 		if (splitDeepColumns) {
-			const size_t fixed = size_t(3) * colorLevels * kBlock * 4 + size_t(h.small_slots) * 16;
+			// sharedWords: one more word per work-item behind the columns (the shared walk of a scene of several objects)
+			const size_t fixed = size_t(3) * colorLevels * kBlock * 4 + size_t(h.small_slots) * 16 + (sharedWords ? size_t(kBlock) * 4 : 0);
 			const size_t room = kHbmBudget > fixed ? kHbmBudget - fixed : 0;
 			const size_t fit = room / perLevel;
 			if (fit < size_t(h.scene_depth) + meshLdsLevels) {
@@ -353,6 +356,10 @@ namespace
 			p.stackSlot = 0;
 		}
 		p.ldsBytes = size_t(p.stackSlot) * 16 + stackBytes;
+		if (sharedWords) {
+			p.wordsOff = uint32_t(stackBytes / 4);
+			p.ldsBytes += size_t(kBlock) * 4;
+		}
 		return p;
 	}
 	// Makes list.dev() hold `ids`.  A list equal to the previous one costs a memcmp; a new one is queued into the
@@ -649,6 +656,15 @@ int acr_hip_upload_scene(acr_hip_ctx *ctx, const acr_scene_soa *s)
 	h.num_triangles = s->num_triangles;
 	memcpy(h.scene_min, s->scene_min, 12);
 	memcpy(h.scene_max, s->scene_max, 12);
+	{
+		// see SceneHeader::zero_dir_misses: finite triangle edges (checked above for intervalOk) and finite matrices
+		bool finite = intervalOk;
+		for (uint32_t i = 0; i < s->num_objects && finite; i++) {
+			for (int k = 0; k < 16; k++) finite = finite && std::isfinite(s->obj_transform[16 * size_t(i) + k]) && std::isfinite(s->obj_inv_transform[16 * size_t(i) + k]);
+			for (int k = 0; k < 9; k++) finite = finite && std::isfinite(s->obj_normal_transform[9 * size_t(i) + k]) && std::isfinite(s->obj_inv_normal_transform[9 * size_t(i) + k]);
+		}
+		h.zero_dir_misses = finite ? 1u : 0u;
+	}
 
 	std::vector<uint4> blob(size_t(h.total_slots) + acr::dev::kBlobPadSlots, make_uint4(0, 0, 0, 0)); // see kBlobPadSlots
 	for (uint32_t i = 0; i < snodeCount; i++)
@@ -1038,15 +1054,20 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	                      f->max_bounces >= 1 && !f->path_keys_dev;
 	// (the variant of that kernel for frames without bounces is compiled for four waves per SIMD, and its columns then
 	// get a quarter of a CU's LDS, the levels above them global memory: not for the launch that may allocate nothing)
-	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave, wantSolo && f->max_bounces == 1 && !staticOnly);
+	// Several objects whose trees are read from HBM: the same kernel, every lane walking the tree over objects for
+	// itself and the wave taking the objects asked for one after the other.
+	const bool wantMulti = !wantSolo && ctx->intervalOk && ctx->leafOrderOk && ctx->traversalMode == ACR_TRAVERSAL_AUTO && ctx->header.num_objects >= 1 &&
+	                       !ctx->soloOff && f->max_bounces >= 1 && !f->path_keys_dev;
+	const LaunchPlan plan = planLds(ctx->header, f->max_bounces > 1 ? f->max_bounces - 1 : 0, true, wantWave, wantSolo && f->max_bounces == 1 && !staticOnly, wantMulti);
 	p.lds_stack_slot = plan.stackSlot;
 	p.lds_cstack_off = plan.cstackOff;
-	p.lds_wave_off = plan.waveOff;
+	p.lds_wave_off = plan.waveOff ? plan.waveOff : plan.wordsOff;
 	// the interval form walks mesh trees that are not LDS-resident near side first, which needs leafOrderOk
 	const bool fast = ctx->intervalOk && ctx->traversalMode != ACR_TRAVERSAL_SIX_PLANE && (plan.ldsMode == 2 || ctx->leafOrderOk);
 	const bool listOnly = fast && ctx->traversalMode == ACR_TRAVERSAL_LIST_PASS;
 	const bool waveKernel = fast && plan.waveOff != 0;
 	const bool soloKernel = fast && wantSolo && plan.ldsMode != 2;
+	const bool multiKernel = fast && wantMulti && !listOnly && plan.ldsMode != 2;
 	if (listOnly && (f->path_keys_dev || f->tile_cycles_dev))
 		return fail(ctx, ACR_ERR_UNSUPPORTED, "ACR_TRAVERSAL_LIST_PASS renders frames only (no path keys, no tile clock ticks)");
 	if (staticOnly && fast && plan.meshGlobLevels)
@@ -1112,7 +1133,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 		p.block_cost = nullptr;
 		measureBlocks = false;
 	}
-	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (soloKernel ? 4 : (fast ? 1 : 0))), grid, plan.ldsBytes, ctx->stream));
+	ACR_HIP_TRY(ctx, acr_dev_launch_render(&p, plan.ldsMode, listOnly ? 2 : (waveKernel ? 3 : (soloKernel ? 4 : (multiKernel ? 5 : (fast ? 1 : 0)))), grid, plan.ldsBytes, ctx->stream));
 	// the list pass that was just queued zeroes the other counter: only now does the next frame switch to it
 	if (fast && !staticOnly) ctx->redoParity ^= 1u;
 	if (tiled) {
@@ -1169,7 +1190,7 @@ static int renderImpl(acr_hip_ctx *ctx, const acr_frame *f, void *screen_dev, ui
 	ctx->stats.interval_traversal = fast ? 1u : 0u;
 	ctx->stats.near_first = (fast && !listOnly && plan.ldsMode != 2) ? 1u : 0u;
 	ctx->stats.wave_tasks = waveKernel ? 1u : 0u;
-	ctx->stats.shared_walk = soloKernel ? 1u : 0u;
+	ctx->stats.shared_walk = (soloKernel || multiKernel) ? 1u : 0u;
 	ctx->lastSlots = tiled ? size_t(f->num_tiles) * f->tile_w * f->tile_h : size_t(f->width) * f->height;
 	return ACR_OK;
 }

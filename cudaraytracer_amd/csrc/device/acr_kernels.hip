@@ -163,6 +163,20 @@ struct SceneMem
 
 struct Ray { vec3 o, d; };
 
+// Rays that hit nothing whatever a traversal does with them, so that the interval kernels need not hand their pixels to
+// the six-plane pass (whose answer is the same, and slow to get on a deep tree):
+//  * a direction with a NaN component (randomHemi and refract produce them from degenerate normals): the local direction
+//    normalize(M d) is NaN in every component for any matrix, cross(d, e2) and the determinant are NaN, no test of
+//    myIntersectRayTriangle (math.h:123-146) is true for a NaN, so it returns true with t = NaN, and `t < info.t`
+//    (geometry.h:123-146) is false: no triangle of no object is ever taken;
+//  * the zero vector (+0 or -0 in every component), in scenes that vouch for it: SceneHeader::zero_dir_misses.
+__device__ __forceinline__ bool hitsNothing(const SceneHeader &sc, const Ray &r)
+{
+	if (r.d.x != r.d.x || r.d.y != r.d.y || r.d.z != r.d.z)
+		return true;
+	return sc.zero_dir_misses && r.d.x == 0.0f && r.d.y == 0.0f && r.d.z == 0.0f;
+}
+
 // Per-ray constants of the slab test: geometry.h:78-86 / bih.h:223-228
 struct SlabArgs
 {
@@ -1073,6 +1087,8 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 {
 	SlabArgs sa;
 	if constexpr (FAST) {
+		if (!KEYS && hitsNothing(sc, r))
+			return false; // info stays as it is: not occluded, no intersection (with KEYS the walk is wanted for its path)
 		if (!(PARALLEL ? parallelRayQualifies(sa, r, kParallelMaxObjects) : sa.initInterval(r))) {
 			bail = true;
 			return false;
@@ -1554,8 +1570,8 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 	SlabArgs sa;
 	sa.o = vec3(0, 0, 0);
 	sa.invD = vec3(1, 1, 1);
-	bool part = active;
-	if (active && !sa.initInterval(r)) {
+	bool part = active && !hitsNothing(sc, r);
+	if (part && !sa.initInterval(r)) {
 		bail = true;
 		part = false;
 	}
@@ -2177,14 +2193,16 @@ __device__ __forceinline__ void soloMerge(SoloFound &a, float t, const vec3 &bar
 __device__ __forceinline__ float shflF(float v, uint32_t src) { return __shfl(v, int(src), 64); }
 
 // Mesh::intersect (geometry.cu:52-61) below the root box test for the rays of a wave, called by all 64 lanes together.
-// wants: this lane has a ray (lr, sa; root: its interval in the mesh's box, which it hits).  R: what the ray found.
+// wants: this lane has a ray (lr, sa; root: its interval in the mesh's box, which it hits).  R: what the ray found
+// (R.any: something nearer than tStart).
 template <class Mem>
 __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint32_t nodeCount, uint32_t triBase, uint32_t triFirst, const LevelColumn &stack,
-                                         bool wants, const Ray &lr, const SlabArgs &sa, const Interval &root, SoloFound &R, uint32_t *nearest)
+                                         bool wants, const Ray &lr, const SlabArgs &sa, const Interval &root, SoloFound &R, uint32_t *nearest,
+                                         float tStart = FLT_MAX)
 {
 	const uint32_t lane = laneNow();
 	const uint64_t below = (1ull << lane) - 1ull;
-	R.t = FLT_MAX;
+	R.t = tStart; // tmpInfo.t as Mesh::intersect finds it: an earlier mesh of the object may have left a hit (scene.cu:418-424)
 	R.bary = vec3(0, 0, 0);
 	R.tri = 0;
 	R.any = false;
@@ -2207,7 +2225,7 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 	unsigned long long dbg[8] = {wants ? 1ull : 0ull, 0, 0, 0, 0, 0, 0, 0};
 #endif
 	waveSync();
-	nearest[lane] = __float_as_uint(FLT_MAX);
+	nearest[lane] = __float_as_uint(tStart);
 	waveSync();
 	for (;;) {
 		uint64_t busy = __ballot(working);
@@ -2322,7 +2340,7 @@ __device__ __forceinline__ void soloWalk(const Mem &mem, uint32_t nodeBase, uint
 // then a single leaf, which Scene::intersect visits without a test: bih.h:209-299 never tests the root box): what a
 // pixel's rays compute is renderSlot's, operation for operation, but the 64 lanes of a wave go through it in step and
 // walk the mesh tree together (soloWalk).  Every lane of the wave makes every call, with or without a ray.
-template <bool ONE, class Mem>
+template <bool ONE, bool MULTI, class Mem>
 __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, const Mem &mem, uint32_t vblock, uint32_t vtid)
 {
 	const SceneHeader &sc = p.scene;
@@ -2331,8 +2349,9 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 	const LevelColumn stack = {reinterpret_cast<float2 *>(ldsF + 2 * threadIdx.x + 2 * sc.scene_depth * kBlock),
 	                           p.mesh_glob + (size_t(blockIdx.x) * kBlock + threadIdx.x), p.mesh_glob_levels, p.mesh_glob_stride};
 
-	// the column of the tree over objects, which nothing walks here: one word per lane of this wave for soloWalk
-	uint32_t *nearest = reinterpret_cast<uint32_t *>(ldsF) + (threadIdx.x & ~63u);
+	// One word per lane of this wave for soloWalk: in the column of the tree over objects where nothing walks that
+	// tree (one object), behind the columns otherwise (the host has made room: planLds).
+	uint32_t *nearest = reinterpret_cast<uint32_t *>(MULTI ? ldsF + p.lds_wave_off : ldsF) + (threadIdx.x & ~63u);
 	// the one object and its one mesh (records are read where they are used; these few numbers stay)
 	const uint32_t os = sc.off_objects;
 	const uint32_t meshId = mem.small(os + 1).w;
@@ -2417,11 +2436,230 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		return length(pw - origin);
 	};
 
+	bool listed = false; // the list pass renders the pixel from the start
+
+	// MULTI: Scene::intersect (scene.cu:204-207) for a scene of several objects.  Every lane walks the tree over objects
+	// for its own ray, in the reference's order and with info.t as it stands (bihTraverseFast, cut where it reaches an
+	// object); whenever lanes stand before an object, the wave takes the objects asked for one after the other, and for
+	// each of them the lanes that asked go through Object::intersect together: the object's meshes one after the other,
+	// every mesh tree walked by the whole wave (soloWalk).  Which objects a ray visits, in which order and with which
+	// info.t is then the reference's, which matters: a bounce ray's direction is not normalised, and the reference compares
+	// its slab distances with world distances all the same.  A ray the interval form cannot serve sends its pixel to the
+	// list pass (no second way in for primary rays here).
+	struct Best
+	{
+		float t;       // info.t
+		bool anyHit;   // `intersected`
+		bool replaced; // info holds a hit: (obj, tri, material)
+		uint32_t obj, tri, material;
+	};
+	constexpr uint32_t kNoObject = 0xFFFFFFFFu;
+	auto traceObjects = [&](bool &active, const Ray &r, bool shadow, float lightT, float distPerT, Best &best) {
+		best.t = shadow ? lightT : FLT_MAX;
+		best.anyHit = false;
+		best.replaced = false;
+		best.obj = best.tri = best.material = 0u;
+		SlabArgs saWorld;
+		saWorld.o = vec3(0, 0, 0);
+		saWorld.invD = vec3(1, 1, 1);
+		// where this lane's walk of the tree over objects stands
+		uint32_t sIdx = 0, sLevel = 0, sPending = 0, item = 0, itemEnd = 0;
+		float sMin = 0.0f, sMax = 0.0f;
+		bool needPop = false, walking = false;
+		if (active && !hitsNothing(sc, r)) {
+			if (!saWorld.initInterval(r)) {
+#ifdef ACR_WALK_DEBUG
+				atomicAdd(&g_walkDebug[12], 1ull);
+				if (__builtin_isnan(r.d.x) || __builtin_isnan(r.d.y) || __builtin_isnan(r.d.z)) atomicAdd(&g_walkDebug[15], 1ull);
+#endif
+				listed = true;
+				active = false;
+			} else {
+				const vec3 smin(sc.scene_min[0], sc.scene_min[1], sc.scene_min[2]), smax(sc.scene_max[0], sc.scene_max[1], sc.scene_max[2]);
+				const Interval box = boxInterval(saWorld, smin, smax);
+				sMin = box.tmin;
+				sMax = box.tmax;
+				walking = true;
+			}
+		}
+		const LevelColumn lc = {reinterpret_cast<float2 *>(ldsF + 2 * threadIdx.x), nullptr, 0u, 0u};
+		auto loadSceneNode = [&](uint32_t i) { return mem.small(sc.off_snodes + i); };
+		// bihTraverseFast up to the next object it hands to its leaf function (kNoObject: the walk is over)
+		auto nextObject = [&]() -> uint32_t {
+			for (;;) {
+				if (item < itemEnd)
+					return item++;
+				if (needPop) {
+					if (sPending == 0)
+						return kNoObject;
+					const uint32_t l = 31u - uint32_t(__clz(int(sPending)));
+					sPending &= ~(1u << l);
+					const float2 b = lc.load(l);
+					sMin = b.x;
+					sMax = b.y;
+					sIdx = 2 * (((sIdx + 1) >> (sLevel - l)) - 1) + 2;
+					sLevel = l + 1;
+					needPop = false;
+				}
+				uint4 n = loadSceneNode(sIdx);
+				bool over = false;
+				while ((n.w & kNodeLeafBit) == 0) {
+					const uint4 childL = loadSceneNode(2 * sIdx + 1), childR = loadSceneNode(2 * sIdx + 2);
+					const uint32_t axis = (n.w >> kNodeAxisShift) & 3u;
+					const float oa = saWorld.o[int(axis)], ia = saWorld.invD[int(axis)];
+					const bool sg = ia < 0;
+					const float tl = (asF(n.x) - oa) * ia;
+					const float tr = (asF(n.y) - oa) * ia;
+					const float tCutFar = sg ? tr : tl, tCutNear = sg ? tl : tr;
+					const float nearSideMax = tCutFar < sMax ? tCutFar : sMax;
+					const float farSideMin = tCutNear > sMin ? tCutNear : sMin;
+					const bool hitNearSide = intervalHit(sMin, nearSideMax, best.t);
+					const bool hitFarSide = intervalHit(farSideMin, sMax, best.t);
+					const bool hitL = sg ? hitFarSide : hitNearSide;
+					const bool hitR = sg ? hitNearSide : hitFarSide;
+					if (hitL || hitR) {
+						const bool takeFarSide = hitL ? sg : !sg;
+						if (hitL && hitR) {
+							sPending |= 1u << sLevel;
+							lc.store(sLevel, takeFarSide ? make_float2(sMin, nearSideMax) : make_float2(farSideMin, sMax));
+						}
+						if (takeFarSide) sMin = farSideMin;
+						else sMax = nearSideMax;
+						sIdx = 2 * sIdx + (hitL ? 1 : 2);
+						sLevel++;
+						n = hitL ? childL : childR;
+					} else {
+						if (sPending == 0) {
+							over = true;
+							break;
+						}
+						const uint32_t l = 31u - uint32_t(__clz(int(sPending)));
+						sPending &= ~(1u << l);
+						const float2 b = lc.load(l);
+						sMin = b.x;
+						sMax = b.y;
+						sIdx = 2 * (((sIdx + 1) >> (sLevel - l)) - 1) + 2;
+						sLevel = l + 1;
+						n = loadSceneNode(sIdx);
+					}
+				}
+				if (over)
+					return kNoObject;
+				item = n.z;
+				itemEnd = n.w & kNodeEndMask;
+				needPop = true;
+			}
+		};
+		for (;;) {
+			uint32_t want = kNoObject;
+			if (walking) {
+				want = nextObject();
+				if (want == kNoObject) walking = false;
+			}
+			uint64_t asking = __ballot(want != kNoObject);
+			if (asking == 0)
+				break;
+			while (asking != 0) {
+				const uint32_t obj = uint32_t(__builtin_amdgcn_readlane(int(want), __ffsll((unsigned long long)asking) - 1));
+				const bool mine = want == obj;
+				asking &= ~__ballot(mine);
+				const uint32_t objSlot = sc.off_objects + obj * kObjectSlots;
+				bool enter = false;
+				if (mine) {
+					// see objectIntersect for the limit
+					const float tLimit = (shadow || best.anyHit) ? best.t * distPerT : FLT_MAX;
+					const uint4 b0 = mem.small(objSlot), b1 = mem.small(objSlot + 1);
+					const uint32_t flags = b0.w;
+					enter = true;
+					if (flags & kObjPrefilter) {
+						const vec3 wmin(asF(b0.x), asF(b0.y), asF(b0.z)), wmax(asF(b1.x), asF(b1.y), asF(b1.z));
+						const Interval wb = boxInterval(saWorld, wmin, wmax);
+						if (!intervalHit(wb.tmin, wb.tmax, tLimit)) enter = false;
+					}
+					if (enter) {
+						uint32_t u0, u1;
+						const mat4 invM = loadMat4(mem, objSlot + 2);
+						const mat3 invN = loadMat3(mem, objSlot + 6, u0, u1);
+						lr.o = (flags & kObjInvAffine) ? translateAffine(invM, r.o) : translate(invM, r.o);
+						lr.d = translaten(invN, r.d);
+						if (!sa.initInterval(lr)) {
+#ifdef ACR_WALK_DEBUG
+							atomicAdd(&g_walkDebug[13], 1ull);
+#endif
+							listed = true;
+							active = walking = false;
+							enter = false;
+						}
+					}
+				}
+				// the object's meshes (the same for every lane: scalar registers)
+				const uint32_t firstMesh = __builtin_amdgcn_readfirstlane(mem.small(objSlot + 1).w);
+				const uint4 counts = mem.small(objSlot + 8);
+				const uint32_t meshBegin = __builtin_amdgcn_readfirstlane(counts.y), meshCount = __builtin_amdgcn_readfirstlane(counts.z);
+				// tmpInfo of scene.cu:418-424
+				float objT = FLT_MAX;
+				uint32_t objTri = 0u, objMaterial = 0u;
+				bool objAny = false;
+				for (uint32_t k = 0; k < meshCount; k++) {
+					uint32_t meshNo = firstMesh;
+					if (k != 0) {
+						const uint4 ids = mem.small(sc.off_objmesh + ((meshBegin + k) >> 2));
+						const uint32_t sel = (meshBegin + k) & 3u;
+						meshNo = __builtin_amdgcn_readfirstlane(sel == 0 ? ids.x : (sel == 1 ? ids.y : (sel == 2 ? ids.z : ids.w)));
+					}
+					const MeshRecord mr = loadMeshRecord(mem, sc, meshNo);
+					const uint32_t mNodeBase = __builtin_amdgcn_readfirstlane(sc.off_mnodes + mr.q1.w);
+					const uint32_t mNodeCount = __builtin_amdgcn_readfirstlane((1u << mr.q2.y) - 1u);
+					const uint32_t mTriFirst = __builtin_amdgcn_readfirstlane(mr.q2.x);
+					bool walks = enter;
+					if (walks) {
+						const vec3 bmin(asF(mr.q0.x), asF(mr.q0.y), asF(mr.q0.z)), bmax(asF(mr.q1.x), asF(mr.q1.y), asF(mr.q1.z));
+						root = boxInterval(sa, bmin, bmax);
+						walks = intervalHit(root.tmin, root.tmax, objT); // geometry.cu:55
+					}
+					SoloFound R;
+					soloWalk(mem, mNodeBase, mNodeCount, sc.off_tris + mTriFirst * kTriSlots, mTriFirst, stack, walks, lr, sa, root, R, nearest, objT);
+					if (walks) {
+						if (R.second < FLT_MAX && R.second <= R.leafTmin) { // the visiting order could have mattered
+#ifdef ACR_WALK_DEBUG
+							atomicAdd(&g_walkDebug[14], 1ull);
+#endif
+							listed = true;
+							active = walking = false;
+							enter = false;
+						} else if (R.any) {
+							objT = R.t;
+							objTri = R.tri;
+							objMaterial = mr.q0.w;
+							objAny = true;
+						}
+					}
+				}
+				if (enter && objAny) {
+					// info.point.position in local space (geometry.h:140), to world (scene.cu:428), its distance (scene.cu:431)
+					const uint32_t flags = mem.small(objSlot).w;
+					const vec3 pl = lr.o + lr.d * objT;
+					const mat4 M = loadMat4(mem, objSlot + 9);
+					const vec3 pw = (flags & kObjFwdAffine) ? translateAffine(M, pl) : translate(M, pl);
+					const float t = length(pw - r.o);
+					if (t < best.t) { // scene.cu:432
+						best.t = t;
+						best.replaced = true;
+						best.obj = obj;
+						best.tri = objTri;
+						best.material = objMaterial;
+					}
+					best.anyHit = true;
+					if (shadow && best.t + epsilon() < lightT) walking = false; // scene.cu:226,266: the answer is fixed
+				}
+			}
+		}
+	};
+
 	// ---- scatterTrace up to the primary ray (renderer.cu:326-372) ----
 	const uint32_t maxBounces = ONE ? 1u : p.max_bounces;
 	float *cstack = ldsF + p.lds_cstack_off + threadIdx.x;
 	bool alive = res.active; // the pixel's path goes on
-	bool listed = false;      // the list pass renders the pixel from the start
 	int index = 0;
 	RandState state;
 	state.v0 = state.v1 = state.v2 = state.v3 = state.v4 = state.d = 0;
@@ -2458,22 +2696,48 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 	for (uint32_t level = 0; level < maxBounces; level++) {
 		if (!ONE && __ballot(alive) == 0)
 			break;
+		vec3 position(0, 0, 0), normal(0, 0, 0), lightSum(0, 0, 0);
+		uint32_t material = 0;
+		SoloFound R;
+		if constexpr (MULTI) {
+			if (alive && level > 0) res.cnt.bounce++;
+			Best best;
+			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
+			traceObjects(alive, r, false, 0.0f, level == 0 ? 1.0f : 1.0f / length(r.d), best);
+			if (alive && !best.anyHit) alive = false; // a miss: renderer.cu:315
+			if (alive) {
+				WorldHit info;
+				info.t = FLT_MAX;
+				info.material = 0;
+				info.prim = 0xFFFFFFFFu;
+				info.position = vec3(0, 0, 0);
+				info.normal = vec3(0, 0, 0);
+				if (best.replaced) objectHitDetails(mem, sc, best.obj, best.tri, best.material, r, info);
+				position = info.position;
+				normal = info.normal;
+				material = info.material;
+				if (level == 0) {
+					LateParams &q = lateParams();
+					if (q.primid) q.primid[outSlot] = info.prim;
+					if (q.hit_t) q.hit_t[outSlot] = info.t;
+					res.cnt.primaryHits++;
+				}
+			}
+		} else {
 		uint32_t enter = 0u;
 		if (alive) {
 			if (level > 0) res.cnt.bounce++;
 			// Scene::intersect: the tree over objects is one leaf holding the one object
 			SlabArgs saWorld;
 			enter = 2u;
-			if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
+			if (hitsNothing(sc, r)) enter = 0u;
+			else if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
 			if (enter == 2u && level == 0) // once more, the way renderSlot tries a primary ray again
 				enter = parallelRayQualifies(saWorld, r, kParallelMaxObjects) ? enterObject(r, saWorld, FLT_MAX, true) : 2u;
 			if (enter == 2u) listed = true;
 			if (enter != 1u) alive = false; // listed, or a miss: renderer.cu:315
 		}
-		SoloFound R;
 		soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive, lr, sa, root, R, nearest);
-		vec3 position(0, 0, 0), normal(0, 0, 0), lightSum(0, 0, 0);
-		uint32_t material = 0;
 		if (alive) {
 			if (R.second < FLT_MAX && R.second <= R.leafTmin) { // the visiting order could have mattered
 				listed = true;
@@ -2509,12 +2773,16 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 				}
 			}
 		}
+		}
 
 		// Scene::lightPoint (scene.cu:273-292), one light after the other for the whole wave
 		for (uint32_t li = 0; li < sc.num_lights; li++) {
 			vec3 c(0, 0, 0);
 			float lightT = 0.0f;
 			uint32_t enterS = 0u;
+			Ray shadowRay; // MULTI
+			shadowRay.o = vec3(0, 0, 0);
+			shadowRay.d = vec3(0, 0, 1);
 			if (alive) {
 				const Light l = loadLight(mem, sc, li);
 				vec3 dir;
@@ -2556,14 +2824,29 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 					Ray sr;
 					sr.o = position;
 					sr.d = dir;
-					SlabArgs saWorld;
-					enterS = saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
-					if (enterS == 2u) {
-						listed = true;
-						alive = false;
+					if constexpr (MULTI) {
+						shadowRay = sr;
+						enterS = 3u; // traced below, by the whole wave
+					} else {
+						SlabArgs saWorld;
+						enterS = hitsNothing(sc, sr) ? 0u : saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
+						if (enterS == 2u) {
+							listed = true;
+							alive = false;
+						}
 					}
 				}
 			}
+			if constexpr (MULTI) {
+				bool traced = alive && enterS == 3u;
+				Best best;
+				traceObjects(traced, shadowRay, true, lightT, 1.0f, best);
+				if (alive && enterS == 3u) {
+					if (!traced) alive = false; // listed
+					else if (best.t + epsilon() < lightT) c = vec3(0, 0, 0); // scene.cu:226,266
+				}
+				if (alive) lightSum += c; // scene.cu:290
+			} else {
 			soloWalk(mem, nodeBase, nodeCount, triBase, triFirst, stack, alive && enterS == 1u, lr, sa, root, R, nearest);
 			if (alive) {
 				if (enterS == 1u) {
@@ -2582,6 +2865,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 					}
 				}
 				if (alive) lightSum += c; // scene.cu:290
+			}
 			}
 		}
 
@@ -2688,7 +2972,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 
 // renderKernel<SMALL_LDS, false, true, false, true> for a scene of one object with one mesh: same grid, same block
 // order, same list pass afterwards.
-template <bool SMALL_LDS, bool ONE>
+template <bool SMALL_LDS, bool ONE, bool MULTI = false>
 __global__ void __launch_bounds__(kBlock, ONE ? ACR_SOLO_WAVES : ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
@@ -2700,7 +2984,7 @@ __global__ void __launch_bounds__(kBlock, ONE ? ACR_SOLO_WAVES : ACR_RENDER_WAVE
 	const uint32_t firstSlot = blockIdx.x * uint32_t(kBlock);
 	const uint32_t gblock = firstSlot / kSlots, vtid = firstSlot % kSlots + threadIdx.x;
 	const uint32_t vblock = p.block_order ? p.block_order[gblock] : gblock;
-	const SlotResult res = renderSlotSolo<ONE>(p, mem, vblock, vtid);
+	const SlotResult res = renderSlotSolo<ONE, MULTI>(p, mem, vblock, vtid);
 	LateParams &q = lateParams();
 	if (res.bail) {
 		const uint32_t at = atomicAdd(q.redo_count, 1u);
@@ -3084,7 +3368,7 @@ namespace
 } // namespace
 
 // fast == 1: interval traversal for the whole grid, then the list pass over whatever it handed back
-// (p->redo_* must be set).  fast == 3: the same with the wave-cooperative kernel (scene whole in LDS, no keys).  fast == 4: the same with the kernel for one deep mesh (renderSoloKernel; the caller has checked the scene and the frame).  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
+// (p->redo_* must be set).  fast == 3: the same with the wave-cooperative kernel (scene whole in LDS, no keys).  fast == 4: the same with the kernel for one deep mesh (renderSoloKernel; the caller has checked the scene and the frame); fast == 5: that kernel's form for up to 64 objects.  fast == 2: the list pass alone (the caller listed the slots).  fast == 0: six-plane
 // traversal for the whole grid.  p->path_keys selects the
 // variants that also record the per-pixel traversal-path key.
 template <bool KEYS>
@@ -3107,6 +3391,7 @@ static hipError_t launchRender(const acr::dev::RenderParams *p, int ldsMode, int
 			if (p->max_bounces == 1) k = ldsMode == 1 ? renderSoloKernel<true, true> : renderSoloKernel<false, true>;
 			else k = ldsMode == 1 ? renderSoloKernel<true, false> : renderSoloKernel<false, false>;
 		}
+		if (fast == 5) k = ldsMode == 1 ? renderSoloKernel<true, false, true> : renderSoloKernel<false, false, true>; // up to 64 objects, trees in HBM
 	}
 	hipError_t e = launchWithLds(k, *p, grid, ldsBytes, stream);
 	if (e != hipSuccess) return e;

@@ -64,6 +64,11 @@ namespace dev
 		uint32_t scene_depth, max_mesh_depth;
 		uint32_t num_objects, num_meshes, num_materials, num_lights, num_triangles;
 		float scene_min[3], scene_max[3];
+		// 1: a ray whose direction is the zero vector (glm::refract's answer to total internal reflection, renderer.cu:299)
+		// hits nothing in this scene, whatever the traversal does with its infinite 1 / d: every object's matrices are
+		// finite, so the local direction is a zero vector too, cross(d, e2) and the determinant (geometry.h:123-146) are
+		// zeros for finite edges, and |det| < 0.001 rejects every triangle.  The kernels then skip the traversal.
+		uint32_t zero_dir_misses;
 	};
 } // namespace dev
 } // namespace acr

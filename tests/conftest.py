@@ -128,6 +128,55 @@ def random_instanced_scene(acr, seed, n_objects=40):
     return d
 
 
+def instanced_cloud_scene(acr, seed, n_objects=10, tris=(30000, 50000, 8000)):
+    """Several objects, each instancing one or two of a few LARGE meshes (clouds of random triangles: their trees do
+    not fit LDS), under random rotations, uniform and non-uniform scales and nested parents; diffuse, mirror-like and
+    translucent materials, two point lights.  Returns ImportData."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    d = acr.ImportData()
+    for k, n in enumerate(tris):
+        c = rng.uniform(-1, 1, (n, 1, 3))
+        p = (c + rng.uniform(-0.12, 0.12, (n, 3, 3))).astype(np.float32).reshape(-1, 3)
+        nrm = rng.normal(size=p.shape)
+        nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        d.meshes.append(dict(positions=p, normals=nrm, indices=np.arange(len(p), dtype=np.uint32).reshape(-1, 3), material=k % 3))
+    d.materials = [dict(diffuse=[0.8, 0.6, 0.3], ambient=[0.02, 0.02, 0.02], specular=[0.1, 0.1, 0.1], refracti=0.0),
+                   dict(diffuse=[0.1, 0.1, 0.1], ambient=[0, 0, 0], specular=[0.9, 0.9, 0.9], refracti=0.0),
+                   dict(diffuse=[0.3, 0.5, 0.9], ambient=[0, 0.01, 0.02], specular=[0.3, 0.3, 0.3], refracti=1.5)]
+
+    def trs(t, axis, angle, s):
+        axis = axis / np.linalg.norm(axis)
+        x, y, z = axis
+        c, si = np.cos(angle), np.sin(angle)
+        r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * si, x * z * (1 - c) + y * si],
+                      [y * x * (1 - c) + z * si, c + y * y * (1 - c), y * z * (1 - c) - x * si],
+                      [z * x * (1 - c) - y * si, z * y * (1 - c) + x * si, c + z * z * (1 - c)]])
+        m = np.eye(4)
+        m[:3, :3] = r * np.asarray(s)[None, :]
+        m[:3, 3] = t
+        return [float(np.float32(v)) for v in m.T.reshape(-1)]  # column-major
+
+    ident = trs([0, 0, 0], np.array([0, 0, 1.0]), 0.0, [1, 1, 1])
+    d.nodes.append(dict(name="<Root>", parent=-1, transform=ident, meshes=[]))
+    for k in range(n_objects):
+        parent = 0 if (k < 3 or rng.random() < 0.7) else int(rng.integers(1, k + 1))
+        scale = [float(rng.uniform(0.6, 1.4))] * 3 if rng.random() < 0.6 else list(rng.uniform(0.5, 1.5, 3))
+        spread = 3.5 if parent == 0 else 1.0
+        t = rng.uniform(-spread, spread, 3)
+        meshes = [int(rng.integers(0, len(d.meshes)))]
+        if rng.random() < 0.3:
+            meshes.append(int(rng.integers(0, len(d.meshes))))
+        d.nodes.append(dict(name=f"Obj{k}", parent=parent, transform=trs(t, rng.normal(size=3), rng.uniform(0, 6.28), scale), meshes=meshes))
+    for k, (pos, e) in enumerate([([6.0, 5.0, 8.0], 6.0), ([-7.0, 2.0, 6.0], 5.0)]):
+        d.nodes.append(dict(name=f"L{k}", parent=0, transform=trs(pos, np.array([0, 0, 1.0]), 0.0, [1, 1, 1]), meshes=[]))
+        d.lights.append(dict(name=f"L{k}", type=0, position=[0, 0, 0], direction=[0, 0, -1], ambient=[e, e, e], diffuse=[e, e, e],
+                             specular=[e, e, e], att=[0.0, 1.0, 0.0], cones=[6.2831855, 6.2831855]))
+    d.nodes.append(dict(name="Cam", parent=0, transform=trs([0.0, 0.0, 12.0], np.array([0, 0, 1.0]), 0.0, [1, 1, 1]), meshes=[]))
+    d.camera = dict(name="Cam", aspect=0.0, hfov=0.7853982, position=[0, 0, 0], up=[0, 1, 0], look_at=[0, 0, -1])
+    return d
+
+
 def duplicate_triangle_scene(acr, n, seed=5, spread=0.3):
     """n random triangles, each present twice (the copies in reverse order) in ONE mesh: every hit is an exact tie
     between two items of the mesh tree, usually in different leaves.  One point light and the camera at (0, 0, 5)."""

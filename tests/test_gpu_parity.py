@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import Built, duplicate_triangle_scene, random_instanced_scene, soup_data
+from conftest import Built, duplicate_triangle_scene, instanced_cloud_scene, random_instanced_scene, soup_data
 
 pytestmark = pytest.mark.gpu
 
@@ -1205,3 +1205,60 @@ def test_shared_walks_exact_ties_and_several_lights(core, acr, orc):
         assert st.shared_walk == 1
         assert_same(img, pid, ht, st, ref)
         assert st.rays_shadow > st.primary_hits  # more than one shadow ray a hit on average
+
+
+@pytest.mark.parametrize("seed,depth", [(3, 12), (8, 14)])
+def test_shared_walks_of_several_objects(core, acr, orc, seed, depth):
+    """Several objects instancing large meshes (trees in HBM; rotations, non-uniform scales, nested parents, objects of
+    two meshes, translucent and mirror-like materials, two lights): the wave goes through the objects one after the
+    other and walks every mesh tree together.  Frames, primitive ids, distances and ray counters equal the oracle's and
+    the one-lane-per-ray kernel's, with 1 and 4 levels, over accumulated frames and through a tile list."""
+    import torch
+    b = Built(acr, orc, instanced_cloud_scene(acr, seed), mesh_depth=depth)
+    load(core, b)
+    w, h = 240, 135
+    for bounces in (1, 4):
+        ref = b.oracle.render(w, h, seed=17, frames=0, max_bounces=bounces)
+        img, pid, ht, st = render(core, w, h, seed=17, frames=0, max_bounces=bounces)
+        assert st.shared_walk == 1 and st.near_first == 1 and st.scene_in_lds == 1
+        assert_same(img, pid, ht, st, ref)
+        assert (pid != 0xFFFFFFFF).mean() > 0.2
+        core.set_traversal(nested=True)
+        try:
+            img1, pid1, ht1, st1 = render(core, w, h, seed=17, frames=0, max_bounces=bounces)
+        finally:
+            core.set_traversal()
+        assert st1.shared_walk == 0
+        assert np.array_equal(img1.view(np.uint32), img.view(np.uint32)) and np.array_equal(pid1, pid)
+    core.resize(w, h)
+    acc = None
+    for k in range(3):
+        acc = b.oracle.render(w, h, seed=50 + k, frames=k, max_bounces=3, screen=acc)["screen"]
+        core.render(w, h, seed=50 + k, frames=k, max_bounces=3)
+    core.sync()
+    assert np.array_equal(core.read_framebuffer().view(np.uint32), acc.view(np.uint32))
+    ref = b.oracle.render(w, h, seed=17, frames=0, max_bounces=2)
+    tw, th = 64, 16
+    tx, ty = (w + tw - 1) // tw, (h + th - 1) // th
+    ids = np.random.default_rng(1).permutation(tx * ty).astype(np.uint32)[:11]
+    tiles = torch.zeros((len(ids), th * tw, 4), dtype=torch.float32, device="cuda")
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        core.render(w, h, seed=17, frames=0, max_bounces=2, tile_ids=ids, tile_w=tw, tile_h=th, screen_dev=C.c_void_p(tiles.data_ptr()))
+        core.sync()
+        assert core.read_stats().shared_walk == 1
+    finally:
+        core.use_own_stream()
+    t = tiles.cpu().numpy().reshape(len(ids), th, tw, 4)
+    for k, tid in enumerate(ids):
+        x0, y0 = (int(tid) % tx) * tw, (int(tid) // tx) * th
+        ww, hh = min(tw, w - x0), min(th, h - y0)
+        assert np.array_equal(t[k, :hh, :ww].view(np.uint32), ref["screen"][y0:y0 + hh, x0:x0 + ww].view(np.uint32))
+    # raw ray queries go through the one-lane-per-ray walk: the same hits
+    rng = np.random.default_rng(3)
+    n = 20000
+    org = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    g, r = core.trace_rays(org, d), b.oracle.trace_rays(org, d)
+    assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"])
+    assert np.array_equal(g["t"].view(np.uint32), r["t"].view(np.uint32))

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--soup", type=int, default=0)
+    ap.add_argument("--clouds", type=int, default=0, help="ten objects instancing three clouds of N, 2 N and N / 2 random triangles (tests/conftest.py: instanced_cloud_scene)")
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--edge", type=float, default=0.1)
     ap.add_argument("--extent", type=float, default=10.0)
@@ -53,7 +54,14 @@ def main():
     import cudaraytracer_amd as acr
 
     t0 = time.perf_counter()
-    if args.soup:
+    if args.clouds:
+        from conftest import instanced_cloud_scene
+        data = instanced_cloud_scene(acr, 3, tris=(args.clouds, 2 * args.clouds, args.clouds // 2))
+        if args.nolights:
+            data.lights = []
+        view, keep = data.pack()
+        scene = acr.Scene(import_view=view, mesh_bih_depth=args.depth)
+    elif args.soup:
         from conftest import soup_data
         data = soup_data(acr, args.soup, seed=1, edge=args.edge, extent=args.extent)
         if args.nolights:
@@ -167,7 +175,7 @@ def main():
         b.record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in evs])
-    out = dict(tag=args.tag or (args.lib or "default"), scene=("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
+    out = dict(tag=args.tag or (args.lib or "default"), scene=("clouds%d/d%d" % (args.clouds, args.depth)) if args.clouds else ("soup%d/d%d" % (args.soup, args.depth)) if args.soup else args.scene,
                size=args.size, bounces=args.bounces, ms_mean=float(ms.mean()), ms_min=float(ms.min()), ms_median=float(np.median(ms)),
                rays=int(rays), grays_per_s=rays / (float(np.median(ms)) * 1e-3) / 1e9, digest=digest,
                six_plane_pixels=st.six_plane_pixels, wave_tasks=st.wave_tasks, shared_walk=st.shared_walk, lds_bytes=st.lds_bytes, lds_mode=st.scene_in_lds, build_s=round(t_build, 2), upload_s=round(t_upload, 2))
@@ -181,6 +189,7 @@ def main():
               "%.2f of %s records tested per trip | rounds: %.1f per walk, lanes present %.3f"
               % (v[0], v[1] / max(v[0], 1), v[1] / max(64 * v[2] / one, 1e-9), v[3] / max(v[0], 1), v[3] / max(64 * v[4] / one, 1e-9),
                  v[5] / max(v[3], 1), "ACR_TRIS_PER_TRIP", v[6] / max(v[0], 1), v[6] / max(64 * v[7] / one, 1e-9)), file=sys.stderr)
+        print("walk debug: pixels listed by the shared walk of several objects: world ray %d (NaN direction %d), local ray %d, visiting order %d" % (v[12], v[15], v[13], v[14]), file=sys.stderr)
         print("walk debug: share of walks with <8, 8-15, 16-31, ..., 256-511, 512+ rounds: " + " ".join("%.4f" % (v[8 + b] / max(v[0], 1)) for b in range(8)), file=sys.stderr)
     dbg = getattr(_capi.hip_lib(), "acr_dev_wave_debug", None)
     if dbg is not None:  # experiment builds (-DACR_WAVE_DEBUG): totals over all launches of this run
