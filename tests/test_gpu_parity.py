@@ -1262,3 +1262,43 @@ def test_shared_walks_of_several_objects(core, acr, orc, seed, depth):
     g, r = core.trace_rays(org, d), b.oracle.trace_rays(org, d)
     assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"])
     assert np.array_equal(g["t"].view(np.uint32), r["t"].view(np.uint32))
+
+
+def test_rays_with_nan_and_zero_directions(core, built, acr, orc):
+    """Rays whose direction has a NaN component, or is the zero vector (what refract returns on total internal
+    reflection, renderer.cu:299), hit nothing in the reference whatever its traversal does with them; the interval
+    kernels say so without a traversal.  Raw ray queries on a scene resident in LDS, on a one-mesh scene and on a scene of
+    several objects in HBM against the oracle, which walks the trees with such rays as the reference does; and frames
+    with bounces of the cloud scene, whose degenerate normals produce NaN directions by the thousand, without listed
+    pixels."""
+    rng = np.random.default_rng(11)
+    scenes = [built["cornell-box-cycles"], Built(acr, orc, soup_data(acr, 60000, seed=9, edge=0.1, extent=1.0), mesh_depth=14),
+              Built(acr, orc, instanced_cloud_scene(acr, 8), mesh_depth=14)]
+    for b in scenes:
+        load(core, b)
+        mn, mx = b.oracle.bounds()
+        n = 3000
+        org = rng.uniform(mn, mx, (n, 3)).astype(np.float32)  # inside the scene's box: every slab term is there to go wrong
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[:500] = 0.0
+        d[250:500, 1] = -0.0
+        for k in range(3):
+            d[500 + 300 * k:800 + 300 * k, k] = np.nan
+        d[1400:1600] = np.nan
+        d[1600:1700, 0] = np.nan
+        d[1600:1700, 2] = 0.0
+        g, r = core.trace_rays(org, d), b.oracle.trace_rays(org, d)
+        assert np.array_equal(g["hit"], r["hit"]) and np.array_equal(g["prim"], r["prim"])
+        assert np.array_equal(g["t"].view(np.uint32), r["t"].view(np.uint32))
+        assert not r["hit"][:1700].any() and r["hit"][1700:].sum() > 100
+    b = scenes[2]
+    w, h = 240, 135
+    ref = b.oracle.render(w, h, seed=5, frames=0, max_bounces=4)
+    for nested in (False, True):
+        core.set_traversal(nested=nested)
+        try:
+            img, pid, ht, st = render(core, w, h, seed=5, frames=0, max_bounces=4)
+        finally:
+            core.set_traversal()
+        assert_same(img, pid, ht, st, ref)
+        assert st.six_plane_pixels <= 2
