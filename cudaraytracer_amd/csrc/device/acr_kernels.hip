@@ -2125,6 +2125,9 @@ __global__ void __launch_bounds__(kBlock, LARGE_LDS ? ACR_RENDER_WAVES : ACR_REN
 #ifndef ACR_SOLO_TRIS_PER_TRIP
 #define ACR_SOLO_TRIS_PER_TRIP 4 // ACR_TRIS_PER_TRIP of this kernel: with four it fits the registers of four waves per SIMD (1.12 ms with 3 and with 5)
 #endif
+#ifndef ACR_MULTI_WAVES
+#define ACR_MULTI_WAVES 3 // the same for the form for several objects (168 VGPRs and 84 bytes of scratch per lane; with two waves and no scratch a fifth slower)
+#endif
 #ifndef ACR_SOLO_WAVES
 #define ACR_SOLO_WAVES 4 // waves per SIMD the kernel is compiled for: 1.21 ms with three (and 52 KB of LDS columns), 1.12 with four (40 KB)
 #endif
@@ -2973,7 +2976,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 // renderKernel<SMALL_LDS, false, true, false, true> for a scene of one object with one mesh: same grid, same block
 // order, same list pass afterwards.
 template <bool SMALL_LDS, bool ONE, bool MULTI = false>
-__global__ void __launch_bounds__(kBlock, ONE ? ACR_SOLO_WAVES : ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
+__global__ void __launch_bounds__(kBlock, ONE ? ACR_SOLO_WAVES : MULTI ? ACR_MULTI_WAVES : ACR_RENDER_WAVES_HBM) renderSoloKernel(const RenderParams p)
 {
 	const SceneHeader &sc = p.scene;
 	SceneMem<SMALL_LDS, false> mem;

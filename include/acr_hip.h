@@ -52,7 +52,7 @@ extern "C" {
                                      reference's visiting order, the six-plane form for the rays it cannot serve; slow, for tests */
 #define ACR_TRAVERSAL_NESTED    3  /* as AUTO, but every frame goes through the kernel in which a lane traces its pixel's rays on its own: AUTO hands
                                      the object tests of frames with bounces on LDS-resident scenes out across the wavefront, and lets the lanes
-                                     of a wavefront share their walks through one deep mesh tree resident in HBM */
+                                     of a wavefront share their walks through mesh trees resident in HBM */
 
 typedef struct acr_hip_ctx acr_hip_ctx;
 
@@ -196,7 +196,7 @@ typedef struct acr_stats {
 	uint32_t block_order;          /* order in which that launch started its blocks of 16 x 16 pixel slots: ACR_BLOCK_ORDER_* */
 	uint32_t near_first;           /* 1 when that launch walked the mesh trees near side first (interval form, trees resident in HBM) */
 	uint32_t wave_tasks;           /* 1 when that launch handed its object tests out across each wavefront (frames with bounces, scene resident in LDS) */
-	uint32_t shared_walk;          /* 1 when the lanes of a wavefront shared their walks through the mesh tree (one object with one mesh resident in HBM) */
+	uint32_t shared_walk;          /* 1 when the lanes of a wavefront shared their walks through the mesh tree (mesh trees resident in HBM, the tree over objects in LDS) */
 } acr_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
