@@ -170,6 +170,8 @@ struct Ray { vec3 o, d; };
 //    myIntersectRayTriangle (math.h:123-146) is true for a NaN, so it returns true with t = NaN, and `t < info.t`
 //    (geometry.h:123-146) is false: no triangle of no object is ever taken;
 //  * the zero vector (+0 or -0 in every component), in scenes that vouch for it: SceneHeader::zero_dir_misses.
+// Asked where such rays can come from: the continuation rays of rayColor (renderer.cu:262-311) and a caller's own rays
+// (traceKernel); primary rays and shadow rays are normalised differences of points.
 __device__ __forceinline__ bool hitsNothing(const SceneHeader &sc, const Ray &r)
 {
 	if (r.d.x != r.d.x || r.d.y != r.d.y || r.d.z != r.d.z)
@@ -1087,8 +1089,6 @@ __device__ __forceinline__ bool sceneIntersect(const Mem &mem, const SceneHeader
 {
 	SlabArgs sa;
 	if constexpr (FAST) {
-		if (!KEYS && hitsNothing(sc, r))
-			return false; // info stays as it is: not occluded, no intersection (with KEYS the walk is wanted for its path)
 		if (!(PARALLEL ? parallelRayQualifies(sa, r, kParallelMaxObjects) : sa.initInterval(r))) {
 			bail = true;
 			return false;
@@ -1388,10 +1388,12 @@ __device__ __forceinline__ SlotResult renderSlot(const RenderParams &p, const Me
 			// Only the first Scene::intersect of a pixel can reach the key: every traversal pads the Path's length
 			// to 2 * MAX_SIZE bits (bih.h:293-297), at least 126 for the depths the key is offered for.
 			if (level == 0) hit = sceneIntersect<false, FAST, true>(mem, sc, r, info, 0.0f, col, bail, &pathRec, 1.0f);
+			else if (FAST && hitsNothing(sc, r)) hit = false;
 			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail);
 		} else {
 			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
-			hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d));
+			if (FAST && level > 0 && hitsNothing(sc, r)) hit = false;
+			else hit = sceneIntersect<false, FAST>(mem, sc, r, info, 0.0f, col, bail, nullptr, level == 0 ? 1.0f : 1.0f / length(r.d));
 			if constexpr (FAST) {
 				if (bail && level == 0) {
 					// a primary ray with an infinite 1 / d, most likely: once more, through the instantiation that admits it
@@ -1570,7 +1572,7 @@ __device__ __forceinline__ bool waveSceneIntersect(const Mem &mem, const SceneHe
 	SlabArgs sa;
 	sa.o = vec3(0, 0, 0);
 	sa.invD = vec3(1, 1, 1);
-	bool part = active && !hitsNothing(sc, r);
+	bool part = active;
 	if (part && !sa.initInterval(r)) {
 		bail = true;
 		part = false;
@@ -1872,7 +1874,7 @@ __device__ __forceinline__ SlotResult renderSlotWave(const RenderParams &p, cons
 				}
 			}
 		} else {
-			hit = waveSceneIntersect<false>(mem, sc, wl, alive, r, info, 0.0f, col, bail);
+			hit = waveSceneIntersect<false>(mem, sc, wl, alive && !hitsNothing(sc, r), r, info, 0.0f, col, bail);
 		}
 		bool ended = false;
 		vec4 tail(0, 0, 0, 1);
@@ -2457,7 +2459,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		uint32_t obj, tri, material;
 	};
 	constexpr uint32_t kNoObject = 0xFFFFFFFFu;
-	auto traceObjects = [&](bool &active, const Ray &r, bool shadow, float lightT, float distPerT, Best &best) {
+	auto traceObjects = [&](bool &active, const Ray &r, bool shadow, float lightT, float distPerT, bool continuation, Best &best) {
 		best.t = shadow ? lightT : FLT_MAX;
 		best.anyHit = false;
 		best.replaced = false;
@@ -2469,7 +2471,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 		uint32_t sIdx = 0, sLevel = 0, sPending = 0, item = 0, itemEnd = 0;
 		float sMin = 0.0f, sMax = 0.0f;
 		bool needPop = false, walking = false;
-		if (active && !hitsNothing(sc, r)) {
+		if (active && !(continuation && hitsNothing(sc, r))) {
 			if (!saWorld.initInterval(r)) {
 #ifdef ACR_WALK_DEBUG
 				atomicAdd(&g_walkDebug[12], 1ull);
@@ -2706,7 +2708,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 			if (alive && level > 0) res.cnt.bounce++;
 			Best best;
 			// slab distances per unit of world distance: 1 for the normalised primary ray, 1 / |d| for a bounce ray
-			traceObjects(alive, r, false, 0.0f, level == 0 ? 1.0f : 1.0f / length(r.d), best);
+			traceObjects(alive, r, false, 0.0f, level == 0 ? 1.0f : 1.0f / length(r.d), level > 0, best);
 			if (alive && !best.anyHit) alive = false; // a miss: renderer.cu:315
 			if (alive) {
 				WorldHit info;
@@ -2733,7 +2735,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 			// Scene::intersect: the tree over objects is one leaf holding the one object
 			SlabArgs saWorld;
 			enter = 2u;
-			if (hitsNothing(sc, r)) enter = 0u;
+			if (!ONE && level > 0 && hitsNothing(sc, r)) enter = 0u;
 			else if (saWorld.initInterval(r)) enter = enterObject(r, saWorld, FLT_MAX, false);
 			if (enter == 2u && level == 0) // once more, the way renderSlot tries a primary ray again
 				enter = parallelRayQualifies(saWorld, r, kParallelMaxObjects) ? enterObject(r, saWorld, FLT_MAX, true) : 2u;
@@ -2832,7 +2834,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 						enterS = 3u; // traced below, by the whole wave
 					} else {
 						SlabArgs saWorld;
-						enterS = hitsNothing(sc, sr) ? 0u : saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
+						enterS = saWorld.initInterval(sr) ? enterObject(sr, saWorld, lightT, false) : 2u;
 						if (enterS == 2u) {
 							listed = true;
 							alive = false;
@@ -2843,7 +2845,7 @@ __device__ __forceinline__ SlotResult renderSlotSolo(const RenderParams &p, cons
 			if constexpr (MULTI) {
 				bool traced = alive && enterS == 3u;
 				Best best;
-				traceObjects(traced, shadowRay, true, lightT, 1.0f, best);
+				traceObjects(traced, shadowRay, true, lightT, 1.0f, false, best);
 				if (alive && enterS == 3u) {
 					if (!traced) alive = false; // listed
 					else if (best.t + epsilon() < lightT) c = vec3(0, 0, 0); // scene.cu:226,266
@@ -3115,7 +3117,7 @@ __global__ void __launch_bounds__(kBlock) traceKernel(const TraceParams p)
 		info.position = vec3(0, 0, 0);
 		info.normal = vec3(0, 0, 0);
 		const Columns col = {ldsF + 2 * threadIdx.x, ldsF + 2 * threadIdx.x + 2 * sc.scene_depth * kBlock, nullptr, 0u, 0u};
-		h = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail);
+		if (!hitsNothing(sc, r)) h = sceneIntersect<false, true>(mem, sc, r, info, 0.0f, col, bail);
 	}
 	if (bail) {
 		info.t = p.tmax ? p.tmax[i] : FLT_MAX;
