@@ -451,7 +451,7 @@ def main():
                 out["also"] = also
         if world == 1:
             tf_ = lambda v: "true" if v else "false"
-            kernel = "renderWaveKernel" if wave_tasks else ("renderSoloKernel<%s>" % tf_(lds_mode >= 1)) if shared_walk else "renderKernel<%s, %s, %s, false, %s>" % (
+            kernel = "renderWaveKernel" if wave_tasks else ("renderSoloKernel<%s, %s, false>" % (tf_(lds_mode >= 1), tf_(MAX_BOUNCES == 1))) if shared_walk else "renderKernel<%s, %s, %s, false, %s>" % (
                 tf_(lds_mode >= 1), tf_(lds_mode == 2), tf_(interval), tf_(interval and MAX_BOUNCES == 1))
             frame_bytes = BYTES_PER_PIXEL * WIDTH * HEIGHT
             # The roofline that binds: with the scene resident in LDS a frame's only HBM traffic is the framebuffer
