@@ -1302,3 +1302,39 @@ def test_rays_with_nan_and_zero_directions(core, built, acr, orc):
             core.set_traversal()
         assert_same(img, pid, ht, st, ref)
         assert st.six_plane_pixels <= 2
+
+
+def test_shared_walks_under_spot_and_directional_lights(core, acr, orc):
+    """The shared-walk kernels carry their own copy of spotLightAccum (scene.cu:234-271): a one-mesh scene and a scene
+    of several objects in HBM under a spot light and a "directional" one, with 1 and 3 levels.  Geometry is held to bit
+    equality with the oracle, radiance to the 1e-4 tolerance that acosf needs (libm against the device library, see
+    test_spot_and_directional_lights); and the frames equal the one-lane-per-ray kernel's bit for bit, which calls the
+    same device acosf."""
+    for data in (soup_data(acr, 60000, seed=9, edge=0.1, extent=1.0), instanced_cloud_scene(acr, 8)):
+        l0 = data.lights[0]
+        l0.update(type=2, direction=[0.1, -0.2, -1.0], cones=[1.2, 1.6])
+        extra = dict(l0)
+        extra.update(name="Dir", type=1, direction=[0.3, 0.2, -1.0], cones=[2.4, 3.0])
+        data.nodes.append(dict(name="Dir", parent=0, transform=[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -2.0, 3.0, 6.0, 1], meshes=[]))
+        data.lights.append(extra)
+        b = Built(acr, orc, data, mesh_depth=14)
+        load(core, b)
+        w, h = 256, 144
+        for bounces in (1, 3):
+            img, pid, ht, st = render(core, w, h, seed=5, frames=0, max_bounces=bounces)
+            assert st.shared_walk == 1
+            ref = b.oracle.render(w, h, seed=5, frames=0, max_bounces=bounces)
+            assert np.array_equal(pid, ref["prim"]) and np.array_equal(ht.view(np.uint32), ref["t"].view(np.uint32))
+            a, r = img[..., :3].astype(np.float64), ref["screen"][..., :3].astype(np.float64)
+            rel = np.abs(a - r) / np.maximum(np.abs(r), 1e-3)
+            assert (rel > 1e-4).mean() < 1e-3
+            assert np.array_equal(img[..., 3], ref["screen"][..., 3])
+            assert (r.sum(axis=2) > 0).mean() > 0.01
+            core.set_traversal(nested=True)
+            try:
+                img1, pid1, ht1, st1 = render(core, w, h, seed=5, frames=0, max_bounces=bounces)
+            finally:
+                core.set_traversal()
+            assert st1.shared_walk == 0
+            assert np.array_equal(img1.view(np.uint32), img.view(np.uint32))
+            assert (st1.rays_shadow, st1.rays_bounce) == (st.rays_shadow, st.rays_bounce)
