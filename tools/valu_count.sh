@@ -11,7 +11,7 @@ import csv,glob,sys,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(glob.glob(sys.argv[1]+"/*counter_collection.csv")[0])):
     k=r["Kernel_Name"]
-    if "renderKernel" in k or "renderQueueKernel" in k or "renderWaveKernel" in k:
+    if "renderKernel" in k or "renderSoloKernel" in k or "renderWaveKernel" in k:
         agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,c in agg.items():
     m={n:sum(v)/len(v) for n,v in c.items()}
