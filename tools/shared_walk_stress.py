@@ -14,8 +14,12 @@ core = acr.HipCore(0)
 w, h = 480, 270
 core.resize(w, h)
 bad = bad1 = listed = frames = 0
-for k, (n, depth) in enumerate([(20000, 13), (100000, 16), (400000, 18)]):
-    data = instanced_cloud_scene(acr, 20 + k, tris=(n, 2 * n, n // 2))
+SCENES = [(20000, 13), (100000, 16), (400000, 18)]
+if len(sys.argv) > 1:  # more scenes: <count> random (triangles, depth, objects) combinations
+    rng = np.random.default_rng(7)
+    SCENES = [(int(rng.integers(3000, 150000)), int(rng.integers(10, 18))) for _ in range(int(sys.argv[1]))]
+for k, (n, depth) in enumerate(SCENES):
+    data = instanced_cloud_scene(acr, 20 + k, n_objects=3 + (5 * k) % 17, tris=(n, 2 * n, n // 2))
     view, keep = data.pack()
     scene = acr.Scene(import_view=view, mesh_bih_depth=depth)
     o = oracle.OracleScene(view, 6, depth)
