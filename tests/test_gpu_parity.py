@@ -1338,3 +1338,29 @@ def test_shared_walks_under_spot_and_directional_lights(core, acr, orc):
             assert st1.shared_walk == 0
             assert np.array_equal(img1.view(np.uint32), img.view(np.uint32))
             assert (st1.rays_shadow, st1.rays_bounce) == (st.rays_shadow, st.rays_bounce)
+
+
+@pytest.mark.parametrize("several", [False, True])
+def test_shared_walks_follow_the_pixel_table(core, acr, orc, several):
+    """DevParams::pixelValues (renderer.cu:344-355) through the shared-walk kernels: frame 0 resets the table to the
+    identity, later frames follow it, on a one-mesh scene and on a scene of several objects in HBM."""
+    import torch
+    data = instanced_cloud_scene(acr, 8) if several else soup_data(acr, 60000, seed=9, edge=0.1, extent=1.0)
+    b = Built(acr, orc, data, mesh_depth=14)
+    load(core, b)
+    w, h = 112, 80
+    core.resize(w, h)
+    for bounces in (1, 3):
+        pm = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        core.render(w, h, seed=9, frames=0, max_bounces=bounces, pixel_values_dev=C.c_void_p(pm.data_ptr()), collect_stats=True)
+        core.sync()
+        assert core.read_stats().shared_walk == 1
+        assert np.array_equal(pm.cpu().numpy(), np.arange(w * h, dtype=np.int32))
+        perm = np.random.default_rng(0).permutation(w * h).astype(np.int32)
+        pm.copy_(torch.from_numpy(perm))
+        torch.cuda.synchronize()
+        core.render(w, h, seed=4, frames=1, max_bounces=bounces, pixel_values_dev=C.c_void_p(pm.data_ptr()))
+        core.sync()
+        base = b.oracle.render(w, h, seed=9, frames=0, max_bounces=bounces)["screen"]
+        ref = b.oracle.render(w, h, seed=4, frames=1, max_bounces=bounces, screen=base, pixel_map=perm)["screen"]
+        assert np.array_equal(core.read_framebuffer().view(np.uint32), ref.view(np.uint32))
