@@ -109,9 +109,10 @@ def test_every_frame_gathered_while_the_next_one_renders(acr, built):
 def test_group_on_scenes_that_list_pixels_and_on_trees_read_from_device_memory(acr, orc, scene_data):
     """bands written in place (acr_frame::tiles_into_frame) by every kind of launch: pixels handed to the six-plane
     list pass (an object with a singular transform), the wave-cooperative kernel (bounces), and mesh trees walked
-    near side first from device memory (a soup), each accumulating over frames with the split re-dealt in between"""
+    near side first from device memory by the lanes of a wave together (a soup; a scene of several large objects), each
+    accumulating over frames with the split re-dealt in between"""
     import copy
-    from conftest import Built, soup_data
+    from conftest import Built, instanced_cloud_scene, soup_data
     d = copy.deepcopy(scene_data["cornell-box-cycles"])
     k = [n["name"] for n in d.nodes].index("short_box")
     m = np.array(d.nodes[k]["transform"], dtype=np.float32).reshape(4, 4)
@@ -119,7 +120,8 @@ def test_group_on_scenes_that_list_pixels_and_on_trees_read_from_device_memory(a
     d.nodes[k]["transform"] = [float(v) for v in m.reshape(-1)]
     cases = [(Built(acr, orc, d), 320, 180, 3, 3),
              (Built(acr, orc, soup_data(acr, 3000, seed=2, edge=0.3, extent=1.5), mesh_depth=10), 200, 150, 1, 2),
-             (Built(acr, orc, soup_data(acr, 60000, seed=3, edge=0.12, extent=2.0), mesh_depth=14), 256, 160, 2, 4)]
+             (Built(acr, orc, soup_data(acr, 60000, seed=3, edge=0.12, extent=2.0), mesh_depth=14), 256, 160, 2, 4),
+             (Built(acr, orc, instanced_cloud_scene(acr, 8), mesh_depth=14), 240, 144, 3, 3)]  # several objects in device memory
     for b, w, h, bounces, members in cases:
         g = acr.HipGroup([0] * members)
         try:
